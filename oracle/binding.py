@@ -1,0 +1,238 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) and, when present, of
+oracle/_ref/libref_check.so (the reference's vendored glm/Eigen arithmetic).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  daisyriot_amd/ never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_REF = os.path.join(_HERE, "_ref", "libref_check.so")
+
+RULE_INTEGRAND = 0
+RULE_RECIPROCITY = 1
+
+
+class _Mesh(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("V", C.c_int),
+                ("normals", C.c_void_p), ("Nn", C.c_int),
+                ("tri_v", C.c_void_p), ("tri_n", C.c_void_p), ("N", C.c_int)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p
+        L.orc_surface.restype = C.c_float
+        L.orc_surface.argtypes = [fp, fp, fp]
+        L.orc_p2p_integrand_literal.restype = C.c_float
+        L.orc_p2p_integrand_literal.argtypes = [C.POINTER(_Mesh), C.c_int, C.c_int]
+        L.orc_patch_records.argtypes = [C.POINTER(_Mesh), fp, fp, fp, fp]
+        L.orc_integrand_rows.argtypes = [C.POINTER(_Mesh), C.c_int, C.c_int, fp]
+        L.orc_uv2xyz.argtypes = [C.POINTER(_Mesh), C.c_int, C.c_float, C.c_float, fp]
+        L.orc_closest_hit.restype = C.c_int
+        L.orc_closest_hit.argtypes = [C.POINTER(_Mesh), fp, fp, fp]
+        L.orc_visibility_count.restype = C.c_int
+        L.orc_visibility_count.argtypes = [C.POINTER(_Mesh), C.c_int, C.c_int, fp, C.c_int, C.c_float]
+        for f in (L.orc_assemble_rows, L.orc_assemble_rows_bvh):
+            f.restype = C.c_int
+            f.argtypes = [C.POINTER(_Mesh), fp, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, fp, u8p, C.c_int]
+        L.orc_sweep_rows.argtypes = [C.c_int, C.c_int, fp, C.c_long, C.c_int, C.c_int, fp, ip, fp, fp, fp, C.c_int]
+        L.orc_residual_sums.argtypes = [C.c_int, C.c_int, fp, fp]
+        L.orc_converge.restype = C.c_int
+        L.orc_converge.argtypes = [C.c_int, C.c_int, fp, fp, ip, fp, fp, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Mesh:
+    """Holds contiguous copies of the MeshS arrays and the C struct over them."""
+
+    def __init__(self, vertices, normals, tri_v, tri_n):
+        self.vertices = _f32(vertices).reshape(-1, 3)
+        self.normals = _f32(normals).reshape(-1, 3)
+        self.tri_v = _i32(tri_v).reshape(-1, 3)
+        self.tri_n = _i32(tri_n).reshape(-1, 3)
+        self.N = self.tri_v.shape[0]
+        self.c = _Mesh(_p(self.vertices), self.vertices.shape[0], _p(self.normals),
+                       self.normals.shape[0], _p(self.tri_v), _p(self.tri_n), self.N)
+
+    @property
+    def ref(self):
+        return C.byref(self.c)
+
+
+def surface(a, b, c):
+    a, b, c = _f32(a), _f32(b), _f32(c)
+    return float(lib().orc_surface(_p(a), _p(b), _p(c)))
+
+
+def p2p_integrand_literal(mesh, i, j):
+    return np.float32(lib().orc_p2p_integrand_literal(mesh.ref, int(i), int(j)))
+
+
+def patch_records(mesh):
+    N = mesh.N
+    cen = np.empty((N, 4, 3), np.float32)
+    sa = np.empty((N, 4), np.float32)
+    nrm = np.empty((N, 3), np.float32)
+    area = np.empty((N,), np.float32)
+    lib().orc_patch_records(mesh.ref, _p(cen), _p(sa), _p(nrm), _p(area))
+    return cen, sa, nrm, area
+
+
+def integrand_rows(mesh, row0=0, nrows=None):
+    nrows = mesh.N - row0 if nrows is None else nrows
+    out = np.empty((nrows, mesh.N), np.float32)
+    lib().orc_integrand_rows(mesh.ref, row0, nrows, _p(out))
+    return out
+
+
+def uv2xyz(mesh, tri, u, v):
+    out = np.empty(3, np.float32)
+    lib().orc_uv2xyz(mesh.ref, int(tri), C.c_float(u), C.c_float(v), _p(out))
+    return out
+
+
+def closest_hit(mesh, org, direction):
+    o, d = _f32(org), _f32(direction)
+    t = np.empty(1, np.float32)
+    tid = lib().orc_closest_hit(mesh.ref, _p(o), _p(d), _p(t))
+    return tid, float(t[0])
+
+
+def visibility_count(mesh, lo, hi, uv, eps=1e-6):
+    uv = _f32(uv).reshape(-1, 2)
+    return lib().orc_visibility_count(mesh.ref, int(lo), int(hi), _p(uv), uv.shape[0], C.c_float(eps))
+
+
+def assemble_rows(mesh, uv, eps=1e-6, rule=RULE_INTEGRAND, row0=0, nrows=None,
+                  want_vis=True, threads=0, bvh=False):
+    uv = _f32(uv).reshape(-1, 2)
+    nrows = mesh.N - row0 if nrows is None else nrows
+    F = np.empty((nrows, mesh.N), np.float32)
+    vis = np.empty((nrows, mesh.N), np.uint8) if want_vis else None
+    fn = lib().orc_assemble_rows_bvh if bvh else lib().orc_assemble_rows
+    used = fn(mesh.ref, _p(uv), uv.shape[0], C.c_float(eps), rule, row0, nrows, _p(F),
+              _p(vis) if want_vis else None, threads)
+    return (F, vis, used) if want_vis else (F, None, used)
+
+
+def sweep_rows(F, M, mat, Rin, B, row0=0, threads=0):
+    """One light pass for the rows held in F (nrows x N). Returns Rout; B updated in place."""
+    F = _f32(F)
+    nrows, N = F.shape
+    Rin = _f32(Rin)
+    S = Rin.shape[1]
+    M = _f32(M)
+    mat = _i32(mat)
+    assert B.dtype == np.float32 and B.flags.c_contiguous and B.shape == (nrows, S)
+    Rout = np.empty((nrows, S), np.float32)
+    lib().orc_sweep_rows(N, S, _p(F), F.strides[0] // 4, row0, nrows, _p(M), _p(mat),
+                         _p(Rin), _p(Rout), _p(B), threads)
+    return Rout
+
+
+def residual_sums(R):
+    R = _f32(R)
+    sums = np.empty(R.shape[1], np.float64)
+    lib().orc_residual_sums(R.shape[0], R.shape[1], _p(R), _p(sums))
+    return sums
+
+
+def converge(F, M, mat, E, threshold, per_bin, max_iters, threads=0):
+    F = _f32(F)
+    N = F.shape[0]
+    R = _f32(E).copy()
+    B = _f32(E).copy()
+    S = R.shape[1]
+    M, mat = _f32(M), _i32(mat)
+    it = lib().orc_converge(N, S, _p(F), _p(M), _p(mat), _p(R), _p(B), C.c_float(threshold),
+                            int(per_bin), int(max_iters), threads)
+    return it, R, B
+
+
+def num_threads():
+    return lib().orc_num_threads()
+
+
+# ---- the reference's vendored glm/Eigen arithmetic (container-built, optional) ----
+_ref = None
+
+
+def ref_available():
+    return os.path.exists(_REF)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        R = C.CDLL(_REF)
+        fp, ip = C.c_void_p, C.c_void_p
+        R.ref_surface.restype = C.c_float
+        R.ref_surface.argtypes = [fp, fp, fp]
+        R.ref_p2p_integrand.restype = C.c_float
+        R.ref_p2p_integrand.argtypes = [fp, fp, ip, ip, C.c_int, C.c_int]
+        R.ref_uv2xyz.argtypes = [fp, ip, C.c_int, C.c_float, C.c_float, fp]
+        R.ref_light_pass.argtypes = [C.c_int, C.c_int, fp, fp, ip, fp, fp, C.c_int]
+        R.ref_sum.restype = C.c_float
+        R.ref_sum.argtypes = [C.c_int, fp]
+        _ref = R
+    return _ref
+
+
+def ref_surface(a, b, c):
+    a, b, c = _f32(a), _f32(b), _f32(c)
+    return float(ref().ref_surface(_p(a), _p(b), _p(c)))
+
+
+def ref_p2p_integrand(mesh, i, j):
+    return np.float32(ref().ref_p2p_integrand(_p(mesh.vertices), _p(mesh.normals), _p(mesh.tri_v),
+                                              _p(mesh.tri_n), int(i), int(j)))
+
+
+def ref_uv2xyz(mesh, tri, u, v):
+    out = np.empty(3, np.float32)
+    ref().ref_uv2xyz(_p(mesh.vertices), _p(mesh.tri_v), int(tri), C.c_float(u), C.c_float(v), _p(out))
+    return out
+
+
+def ref_light_pass(F, M, mat, R, B, mode):
+    F, M, mat = _f32(F), _f32(M), _i32(mat)
+    R, B = _f32(R).copy(), _f32(B).copy()
+    ref().ref_light_pass(F.shape[0], R.shape[1], _p(F), _p(M), _p(mat), _p(R), _p(B), int(mode))
+    return R, B
+
+
+def ref_sum(x):
+    x = _f32(x)
+    return float(ref().ref_sum(x.size, _p(x)))

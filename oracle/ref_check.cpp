@@ -1,0 +1,157 @@
+/*
+ * ref_check.cpp -- evaluates the hot path's arithmetic through the REFERENCE'S
+ * OWN vendored third-party sources (glm 0.9.8.4 and Eigen 3.2.10 under
+ * /root/reference/libraries), compiled where they lie.  Output goes only to
+ * oracle/_ref/ (git-ignored).  It exists to pin oracle.c:
+ *   - the integrand is evaluated with glm::normalize / dot / cross / length at
+ *     the call sites of vs/triangle_math.cpp:11-74 and
+ *     vs/OptixPrimeFunctionality.cpp:133-161 -> must equal oracle.c bit for bit;
+ *   - the light pass is evaluated with Eigen::SparseMatrix<float> * VectorXf,
+ *     cwiseProduct and MatrixXf * VectorXf exactly as vs/Lightning.h:196-226 and
+ *     :342-349 write them -> sparse product must equal oracle.c bit for bit.
+ *
+ * The reference's first-party files themselves are NOT built: triangle_math.cpp
+ * needs <OptiX_world.h> and Lightning.h needs the OptiX Prime class; the OptiX
+ * SDK is absent from this image and is not substituted (DESIGN.md "Oracle").
+ *
+ * TEST INFRASTRUCTURE ONLY.
+ */
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include <glm/glm.hpp>
+#include <Eigen/Dense>
+#include <Eigen/Sparse>
+
+namespace {
+
+struct Mesh {
+    const float* vtx; const float* nrm; const int32_t* tv; const int32_t* tn;
+    glm::vec3 v(int tri, int c) const { const float* p = vtx + 3 * (long)tv[3 * (long)tri + c]; return glm::vec3(p[0], p[1], p[2]); }
+    glm::vec3 n(int tri, int c) const { const float* p = nrm + 3 * (long)tn[3 * (long)tri + c]; return glm::vec3(p[0], p[1], p[2]); }
+};
+
+float area_of(const glm::vec3& a, const glm::vec3& b, const glm::vec3& c) {
+    glm::vec3 ab = b - a, ac = c - a;
+    return 0.5 * glm::length(glm::cross(ab, ac));
+}
+
+struct Quarter { glm::vec3 p[3]; };
+
+void quarters(const Mesh& m, int tri, Quarter q[4]) {
+    glm::vec3 a = m.v(tri, 0), b = m.v(tri, 1), c = m.v(tri, 2);
+    glm::vec3 mab = ((b - a) / 2.0f) + a;
+    glm::vec3 mac = ((c - a) / 2.0f) + a;
+    glm::vec3 mcb = ((b - c) / 2.0f) + c;
+    q[0] = Quarter{ { a, mac, mab } };
+    q[1] = Quarter{ { mac, c, mcb } };
+    q[2] = Quarter{ { mab, mcb, b } };
+    q[3] = Quarter{ { mab, mcb, mac } };
+}
+
+glm::vec3 third_sum(const Quarter& q) {
+    glm::vec3 s = (q.p[0] + q.p[1] + q.p[2]);
+    return glm::vec3(s.x / 3, s.y / 3, s.z / 3);
+}
+
+glm::vec3 patch_normal(const Mesh& m, int tri) {
+    glm::vec3 s = (m.n(tri, 0) + m.n(tri, 1) + m.n(tri, 2));
+    s = glm::vec3(s.x / 3, s.y / 3, s.z / 3);
+    return glm::normalize(s);
+}
+
+float point_term(const glm::vec3& op, const glm::vec3& on, const glm::vec3& dp, const glm::vec3& dn, float surf) {
+    float out = 0;
+    float c1 = glm::dot(on, glm::normalize(dp - op));
+    float c2 = glm::dot(dn, glm::normalize(op - dp));
+    if (c1 > 0 && c2 > 0) {
+        float len = glm::length(dp - op);
+        out = ((c1 * c2) / (powf(len, 2) * 3.14159265358979323846f)) * surf;
+    }
+    return out;
+}
+
+}  // namespace
+
+extern "C" {
+
+float ref_surface(const float* a, const float* b, const float* c) {
+    return area_of(glm::vec3(a[0], a[1], a[2]), glm::vec3(b[0], b[1], b[2]), glm::vec3(c[0], c[1], c[2]));
+}
+
+float ref_p2p_integrand(const float* vtx, const float* nrm, const int32_t* tv, const int32_t* tn, int i, int j) {
+    Mesh m{ vtx, nrm, tv, tn };
+    Quarter qi[4], qj[4];
+    quarters(m, i, qi);
+    quarters(m, j, qj);
+    glm::vec3 ni = patch_normal(m, i), nj = patch_normal(m, j);
+    glm::vec3 ci[4], cj[4];
+    for (int k = 0; k < 4; k++) { ci[k] = third_sum(qi[k]); cj[k] = third_sum(qj[k]); }
+    float acc = 0;
+    for (int s = 0; s < 4; s++)
+        for (int t = 0; t < 4; t++)
+            acc = acc + point_term(ci[s], ni, cj[t], nj,
+                                   area_of(qi[s].p[0], qi[s].p[1], qi[s].p[2]) * area_of(qj[t].p[0], qj[t].p[1], qj[t].p[2]));
+    return acc / area_of(m.v(i, 0), m.v(i, 1), m.v(i, 2));
+}
+
+void ref_uv2xyz(const float* vtx, const int32_t* tv, int tri, float u, float v, float* out) {
+    Mesh m{ vtx, nullptr, tv, nullptr };
+    glm::vec3 a = m.v(tri, 0), b = m.v(tri, 1), c = m.v(tri, 2);
+    glm::vec3 p = a + u * (b - a) + v * (c - a);
+    out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+
+/* One light pass through Eigen, written as Lightning.h writes it.
+ * F dense N x N row-major -> triplets<double> -> SparseMatrix<float> (col-major),
+ * R, B: N x S patch-major.  mode 0: spectral (per-patch MatrixXf * VectorXf,
+ * Lightning.h:196-226); mode 1: RGB (cwiseProduct with rho = diag(M),
+ * Lightning.h:342-349). */
+void ref_light_pass(int N, int S, const float* F, const float* M, const int32_t* mat,
+                    float* R, float* B, int mode) {
+    typedef Eigen::SparseMatrix<float> SpMat;
+    typedef Eigen::Triplet<double> Tripl;
+    std::vector<Tripl> trip;
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++)
+            if (F[(long)i * N + j] != 0.0f) trip.push_back(Tripl(i, j, (double)F[(long)i * N + j]));
+    SpMat RadMat(N, N);
+    RadMat.setFromTriplets(trip.begin(), trip.end());
+
+    std::vector<Eigen::VectorXf> residual(S), light(S);
+    for (int s = 0; s < S; s++) {
+        residual[s] = Eigen::VectorXf(N); light[s] = Eigen::VectorXf(N);
+        for (int i = 0; i < N; i++) { residual[s][i] = R[(long)i * S + s]; light[s][i] = B[(long)i * S + s]; }
+    }
+    if (mode == 1) {
+        for (int s = 0; s < S; s++) {
+            Eigen::VectorXf rho(N);
+            for (int i = 0; i < N; i++) rho[i] = M[(long)mat[i] * S * S + s * S + s];
+            residual[s] = (RadMat * residual[s]).cwiseProduct(rho);
+            light[s] = light[s] + residual[s];
+        }
+    } else {
+        std::vector<Eigen::VectorXf> bounced(S);
+        for (int s = 0; s < S; s++) bounced[s] = (RadMat * residual[s]);
+        for (int i = 0; i < N; i++) {
+            Eigen::MatrixXf Mi(S, S);
+            for (int a = 0; a < S; a++) for (int b = 0; b < S; b++) Mi(a, b) = M[(long)mat[i] * S * S + a * S + b];
+            Eigen::VectorXf row(S);
+            for (int s = 0; s < S; s++) row[s] = bounced[s][i];
+            Eigen::VectorXf res = Mi * row;
+            for (int s = 0; s < S; s++) residual[s][i] = res[s];
+        }
+        for (int s = 0; s < S; s++) light[s] = light[s] + residual[s];
+    }
+    for (int s = 0; s < S; s++)
+        for (int i = 0; i < N; i++) { R[(long)i * S + s] = residual[s][i]; B[(long)i * S + s] = light[s][i]; }
+}
+
+/* Eigen's VectorXf::sum() as check_convergence uses it (Lightning.h:255-261) */
+float ref_sum(int n, const float* x) {
+    Eigen::Map<const Eigen::VectorXf> v(x, n);
+    return v.sum();
+}
+
+}  // extern "C"
