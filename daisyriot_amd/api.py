@@ -1,0 +1,255 @@
+"""ctypes binding of libdaisyriot_hip.so (include/daisyriot_hip.h).
+
+This is the only way Python reaches the hot path: every call goes through the
+C ABI.  There is no CPU fallback -- if the HIP library is missing or a call
+fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdaisyriot_hip.so")
+
+RULE_INTEGRAND = 0       # ini cuda_on = true  (vs/OptixPrimeFunctionality.cpp:6-34)
+RULE_RECIPROCITY = 1     # ini cuda_on = false (vs/OptixPrimeFunctionality.cpp:311-366)
+RAYS_PER_PATCH = 50      # vs/Defines.h:25
+ORIGIN_EPS = 1e-6        # vs/OptixPrimeFunctionality.cpp:194
+MAX_BINS = 16
+
+EXPORTS = [
+    "dr_last_error", "dr_context_create", "dr_context_destroy", "dr_set_stream", "dr_set_shard",
+    "dr_get_shard", "dr_scene_set_mesh", "dr_formfactors_assemble", "dr_formfactors_integrand_only",
+    "dr_formfactors_read_rows", "dr_visibility_read_rows", "dr_formfactors_load_rows", "dr_solver_init",
+    "dr_solver_step", "dr_solver_converge", "dr_solver_reset", "dr_solver_read", "dr_solver_residual_sums",
+    "dr_comm_unique_id", "dr_comm_init", "dr_get_info", "dr_profile_enable", "dr_profile_reset",
+    "dr_synchronize", "dr_debug_read_bvh",
+]
+
+
+class DaisyRiotError(RuntimeError):
+    pass
+
+
+class Info(C.Structure):
+    _fields_ = [("N", C.c_int), ("S", C.c_int), ("rank", C.c_int), ("world", C.c_int), ("row0", C.c_int),
+                ("nrows", C.c_int), ("rows_per_rank", C.c_int), ("n_bvh_nodes", C.c_int),
+                ("ld_F", C.c_size_t), ("bytes_F", C.c_size_t), ("last_assemble_ms", C.c_double),
+                ("last_bvh_ms", C.c_double), ("pairs_traced", C.c_uint64), ("sweep_launches", C.c_uint64),
+                ("sweep_ms_total", C.c_double)]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise DaisyRiotError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(make -C daisyriot_amd/csrc). There is no CPU fallback." % path)
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp, i = C.c_void_p, C.c_int
+    L.dr_last_error.restype = C.c_char_p
+    L.dr_context_create.argtypes = [i, C.POINTER(vp)]
+    L.dr_context_destroy.argtypes = [vp]
+    L.dr_set_stream.argtypes = [vp, vp]
+    L.dr_set_shard.argtypes = [vp, i, i]
+    L.dr_get_shard.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    L.dr_scene_set_mesh.argtypes = [vp, vp, i, vp, i, vp, vp, i]
+    L.dr_formfactors_assemble.argtypes = [vp, vp, i, C.c_float, i, i]
+    L.dr_formfactors_integrand_only.argtypes = [vp]
+    L.dr_formfactors_read_rows.argtypes = [vp, i, i, vp]
+    L.dr_visibility_read_rows.argtypes = [vp, i, i, vp]
+    L.dr_formfactors_load_rows.argtypes = [vp, i, i, vp]
+    L.dr_solver_init.argtypes = [vp, i, vp, vp, i, vp]
+    L.dr_solver_step.argtypes = [vp, i, C.POINTER(C.c_float)]
+    L.dr_solver_converge.argtypes = [vp, C.c_float, i, i, C.POINTER(i)]
+    L.dr_solver_reset.argtypes = [vp]
+    L.dr_solver_read.argtypes = [vp, vp, vp]
+    L.dr_solver_residual_sums.argtypes = [vp, vp]
+    L.dr_comm_unique_id.argtypes = [vp]
+    L.dr_comm_init.argtypes = [vp, vp, i, i]
+    L.dr_get_info.argtypes = [vp, C.POINTER(Info)]
+    L.dr_profile_enable.argtypes = [vp, i]
+    L.dr_profile_reset.argtypes = [vp]
+    L.dr_synchronize.argtypes = [vp]
+    L.dr_debug_read_bvh.argtypes = [vp, vp, i]
+    for name in EXPORTS:
+        if name != "dr_last_error":
+            getattr(L, name).restype = i
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def comm_unique_id():
+    L = load_library()
+    buf = np.zeros(128, np.uint8)
+    rc = L.dr_comm_unique_id(_p(buf))
+    if rc:
+        raise DaisyRiotError("dr_comm_unique_id: %s" % L.dr_last_error().decode())
+    return buf
+
+
+class Context:
+    """One GPU's worth of the hot path.  Mirrors the call order of the reference:
+    MeshS -> OptixPrimeFunctionality(mesh) -> Lightning (initMat, reset, passes)."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        self._chk(self.L.dr_context_create(int(device), C.byref(h)), "dr_context_create")
+        self.h = h
+        self.N = 0
+        self.S = 0
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise DaisyRiotError("%s failed (%d): %s" % (what, rc, self.L.dr_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.dr_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- configuration
+    def set_stream(self, hip_stream_ptr):
+        self._chk(self.L.dr_set_stream(self.h, C.c_void_p(hip_stream_ptr)), "dr_set_stream")
+
+    def set_shard(self, rank, world):
+        self._chk(self.L.dr_set_shard(self.h, int(rank), int(world)), "dr_set_shard")
+
+    def shard(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.L.dr_get_shard(self.h, C.byref(a), C.byref(b), C.byref(c)), "dr_get_shard")
+        return a.value, b.value, c.value
+
+    def comm_init(self, id128, rank, world):
+        id128 = np.ascontiguousarray(id128, dtype=np.uint8)
+        assert id128.size == 128
+        self._chk(self.L.dr_comm_init(self.h, _p(id128), int(rank), int(world)), "dr_comm_init")
+
+    # -- scene
+    def set_mesh(self, vertices, normals, tri_v, tri_n):
+        v, n = _f32(vertices).reshape(-1, 3), _f32(normals).reshape(-1, 3)
+        tv, tn = _i32(tri_v).reshape(-1, 3), _i32(tri_n).reshape(-1, 3)
+        if tv.shape != tn.shape:
+            raise DaisyRiotError("tri_v and tri_n differ in shape")
+        self._chk(self.L.dr_scene_set_mesh(self.h, _p(v), v.shape[0], _p(n), n.shape[0], _p(tv), _p(tn), tv.shape[0]),
+                  "dr_scene_set_mesh")
+        self.N = tv.shape[0]
+
+    # -- form factors
+    def assemble(self, uv, eps=ORIGIN_EPS, rule=RULE_INTEGRAND, keep_visibility=False):
+        uv = _f32(uv).reshape(-1, 2)
+        self._chk(self.L.dr_formfactors_assemble(self.h, _p(uv), uv.shape[0], C.c_float(eps), int(rule),
+                                                 int(bool(keep_visibility))), "dr_formfactors_assemble")
+
+    def integrand_only(self):
+        self._chk(self.L.dr_formfactors_integrand_only(self.h), "dr_formfactors_integrand_only")
+
+    def read_rows(self, row0, nrows):
+        out = np.empty((nrows, self.N), np.float32)
+        self._chk(self.L.dr_formfactors_read_rows(self.h, int(row0), int(nrows), _p(out)), "dr_formfactors_read_rows")
+        return out
+
+    def read_visibility(self, row0, nrows):
+        out = np.empty((nrows, self.N), np.uint8)
+        self._chk(self.L.dr_visibility_read_rows(self.h, int(row0), int(nrows), _p(out)), "dr_visibility_read_rows")
+        return out
+
+    def load_rows(self, row0, F):
+        F = _f32(F)
+        assert F.ndim == 2 and F.shape[1] == self.N
+        self._chk(self.L.dr_formfactors_load_rows(self.h, int(row0), F.shape[0], _p(F)), "dr_formfactors_load_rows")
+
+    # -- solver
+    def solver_init(self, E, M, mat_of_patch):
+        E, M, mat = _f32(E), _f32(M), _i32(mat_of_patch)
+        if E.ndim == 1:
+            E = E.reshape(-1, 1)
+        S = E.shape[1]
+        if M.ndim == 1:
+            M = M.reshape(-1, 1, 1)
+        if E.shape[0] != self.N or mat.shape[0] != self.N or M.shape[1:] != (S, S):
+            raise DaisyRiotError("solver input shapes do not match N=%d S=%d" % (self.N, S))
+        self._chk(self.L.dr_solver_init(self.h, S, _p(E), _p(M), M.shape[0], _p(mat)), "dr_solver_init")
+        self.S = S
+
+    def step(self, n_passes=1, want_sum=False):
+        if want_sum:
+            out = C.c_float()
+            self._chk(self.L.dr_solver_step(self.h, int(n_passes), C.byref(out)), "dr_solver_step")
+            return out.value
+        self._chk(self.L.dr_solver_step(self.h, int(n_passes), None), "dr_solver_step")
+        return None
+
+    def converge(self, threshold, per_bin=False, max_iters=10000):
+        it = C.c_int()
+        self._chk(self.L.dr_solver_converge(self.h, C.c_float(threshold), int(bool(per_bin)), int(max_iters),
+                                            C.byref(it)), "dr_solver_converge")
+        return it.value
+
+    def reset(self):
+        self._chk(self.L.dr_solver_reset(self.h), "dr_solver_reset")
+
+    def read(self, B=True, R=True):
+        b = np.zeros((self.N, self.S), np.float32) if B else None
+        r = np.zeros((self.N, self.S), np.float32) if R else None
+        self._chk(self.L.dr_solver_read(self.h, _p(b) if B else None, _p(r) if R else None), "dr_solver_read")
+        return b, r
+
+    def residual_sums(self):
+        s = np.zeros(MAX_BINS, np.float64)
+        self._chk(self.L.dr_solver_residual_sums(self.h, _p(s)), "dr_solver_residual_sums")
+        return s[:self.S].copy()
+
+    # -- measurement
+    def info(self):
+        o = Info()
+        self._chk(self.L.dr_get_info(self.h, C.byref(o)), "dr_get_info")
+        return o
+
+    def profile(self, on=True):
+        self._chk(self.L.dr_profile_enable(self.h, int(bool(on))), "dr_profile_enable")
+
+    def profile_reset(self):
+        self._chk(self.L.dr_profile_reset(self.h), "dr_profile_reset")
+
+    def read_bvh(self):
+        n = self.info().n_bvh_nodes
+        dt = np.dtype([("lo", np.float32, 3), ("hi", np.float32, 3), ("skip", np.int32), ("tri", np.int32)])
+        out = np.zeros(n, dt)
+        self._chk(self.L.dr_debug_read_bvh(self.h, _p(out), n), "dr_debug_read_bvh")
+        return out
+
+    def synchronize(self):
+        self._chk(self.L.dr_synchronize(self.h), "dr_synchronize")

@@ -1,0 +1,559 @@
+// dr_api.cpp -- implementation of include/daisyriot_hip.h (the drop-in boundary).
+#include "../../include/daisyriot_hip.h"
+#include "dr_comm.h"
+#include "dr_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace dr;
+
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+}  // namespace
+
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(e_ == hipErrorOutOfMemory ? DR_ERR_NOMEM : DR_ERR_DEVICE, "%s failed: %s", #x, \
+                        hipGetErrorString(e_));                                                     \
+    } while (0)
+#define CTX(c)                                                         \
+    do {                                                               \
+        if (!(c)) return fail(DR_ERR_INVALID, "null context");         \
+        HIPCHK(hipSetDevice((c)->device));                             \
+    } while (0)
+
+struct dr_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    int rank = 0, world = 1;
+    // scene
+    int N = 0, V = 0, Nn = 0;
+    float *d_vtx = nullptr, *d_nrm = nullptr;
+    int *d_tv = nullptr, *d_tn = nullptr;
+    PatchRec* d_patch = nullptr;
+    TriRec* d_tri = nullptr;
+    BvhNode* d_bvh = nullptr;
+    int n_nodes = 0;
+    // shard
+    int rpr = 0, row0 = 0, nrows = 0;
+    size_t ldF = 0;
+    float* d_F = nullptr;
+    size_t F_floats = 0;
+    bool have_F = false;
+    unsigned char* d_vis = nullptr;
+    float* d_uv = nullptr;
+    unsigned long long* d_counter = nullptr;
+    // solver
+    int S = 0, n_mat = 0;
+    float *d_M = nullptr, *d_E = nullptr, *d_B = nullptr, *d_R[2] = { nullptr, nullptr };
+    int* d_mat = nullptr;
+    double* d_sums = nullptr;
+    int cur = 0;
+    bool have_solver = false;
+    Comm comm;
+    // measurement
+    double last_assemble_ms = 0, last_bvh_ms = 0;
+    unsigned long long pairs_traced = 0;
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    unsigned long long sweep_launches = 0;
+    double sweep_ms_total = 0;
+};
+
+namespace {
+
+void free_F(dr_context* c) {
+    hipFree(c->d_F); c->d_F = nullptr; c->F_floats = 0; c->have_F = false;
+    hipFree(c->d_vis); c->d_vis = nullptr;
+}
+void free_solver(dr_context* c) {
+    hipFree(c->d_M); hipFree(c->d_E); hipFree(c->d_B); hipFree(c->d_R[0]); hipFree(c->d_R[1]);
+    hipFree(c->d_mat); hipFree(c->d_sums);
+    c->d_M = c->d_E = c->d_B = c->d_R[0] = c->d_R[1] = nullptr; c->d_mat = nullptr; c->d_sums = nullptr;
+    c->have_solver = false;
+}
+void free_scene(dr_context* c) {
+    hipFree(c->d_vtx); hipFree(c->d_nrm); hipFree(c->d_tv); hipFree(c->d_tn);
+    hipFree(c->d_patch); hipFree(c->d_tri); hipFree(c->d_bvh);
+    c->d_vtx = c->d_nrm = nullptr; c->d_tv = c->d_tn = nullptr;
+    c->d_patch = nullptr; c->d_tri = nullptr; c->d_bvh = nullptr; c->N = 0;
+}
+
+void recompute_shard(dr_context* c) {
+    if (c->N <= 0) return;
+    int per = (c->N + c->world - 1) / c->world;
+    c->rpr = ((per + SHARD_ALIGN - 1) / SHARD_ALIGN) * SHARD_ALIGN;
+    c->row0 = c->rank * c->rpr;
+    c->nrows = std::max(0, std::min(c->N - c->row0, c->rpr));
+    c->ldF = (size_t)c->world * c->rpr;
+}
+
+int ensure_F(dr_context* c) {
+    size_t need = (size_t)std::max(c->nrows, 1) * c->ldF;
+    if (c->d_F && c->F_floats == need) return DR_OK;
+    free_F(c);
+    hipError_t e = hipMalloc(&c->d_F, need * sizeof(float));
+    if (e != hipSuccess) {
+        c->d_F = nullptr;
+        return fail(DR_ERR_NOMEM, "F shard of %d x %zu floats (%.2f GB) does not fit: %s", c->nrows, c->ldF,
+                    need * 4.0 / 1e9, hipGetErrorString(e));
+    }
+    c->F_floats = need;
+    return DR_OK;
+}
+
+// drain the profiled event pairs into the running totals
+void drain_events(dr_context* c) {
+    for (size_t i = 0; i < c->ev_used; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second) == hipSuccess) {
+            c->sweep_ms_total += ms;
+            c->sweep_launches++;
+        }
+    }
+    c->ev_used = 0;
+}
+
+int sweep_once(dr_context* c) {
+    SweepParams p;
+    p.N = c->N; p.S = c->S; p.rpr = c->rpr; p.world = c->world; p.row0 = c->row0; p.nrows = c->nrows;
+    p.ldF = c->ldF; p.F = c->d_F; p.Rin = c->d_R[c->cur]; p.Rout = c->d_R[c->cur ^ 1]; p.rank = c->rank;
+    p.B = c->d_B; p.M = c->d_M; p.mat = c->d_mat; p.n_mat = c->n_mat;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profile) {
+        if (c->ev_used == c->ev_pool.size()) {
+            if (c->ev_pool.size() >= 4096) {      // bounded pool: fold what has completed
+                HIPCHK(hipStreamSynchronize(c->stream));
+                drain_events(c);
+            } else {
+                hipEvent_t a, b;
+                HIPCHK(hipEventCreate(&a));
+                HIPCHK(hipEventCreate(&b));
+                c->ev_pool.push_back({ a, b });
+            }
+        }
+        e0 = c->ev_pool[c->ev_used].first; e1 = c->ev_pool[c->ev_used].second;
+        c->ev_used++;
+        HIPCHK(hipEventRecord(e0, c->stream));
+    }
+    HIPCHK(launch_sweep(c->stream, p));
+    if (c->profile) HIPCHK(hipEventRecord(e1, c->stream));
+    if (c->world > 1) {
+        std::string err = comm_allgather_inplace(c->comm, c->d_R[c->cur ^ 1], (size_t)c->S * c->rpr, c->stream);
+        if (!err.empty()) return fail(DR_ERR_COMM, "%s", err.c_str());
+    }
+    c->cur ^= 1;
+    return DR_OK;
+}
+
+int read_sums(dr_context* c, double* sums) {
+    HIPCHK(launch_colsums(c->stream, c->d_R[c->cur], c->world, c->S, c->rpr, c->d_sums));
+    HIPCHK(hipMemcpyAsync(sums, c->d_sums, sizeof(double) * c->S, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dr_last_error(void) { return g_err.c_str(); }
+
+int dr_context_create(int device_id, dr_context** out) {
+    if (!out) return fail(DR_ERR_INVALID, "out is null");
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) return fail(DR_ERR_INVALID, "device %d out of range (0..%d)", device_id, n - 1);
+    HIPCHK(hipSetDevice(device_id));
+    dr_context* c = new dr_context();
+    c->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(DR_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    c->stream = c->own_stream;
+    e = hipMalloc(&c->d_counter, sizeof(unsigned long long));
+    if (e != hipSuccess) { hipStreamDestroy(c->own_stream); delete c; return fail(DR_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
+    *out = c;
+    return DR_OK;
+}
+
+int dr_context_destroy(dr_context* c) {
+    if (!c) return DR_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    comm_destroy(c->comm);
+    free_solver(c); free_F(c); free_scene(c);
+    hipFree(c->d_uv); hipFree(c->d_counter);
+    for (auto& p : c->ev_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+    return DR_OK;
+}
+
+int dr_set_stream(dr_context* c, void* hip_stream) {
+    CTX(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return DR_OK;
+}
+
+int dr_set_shard(dr_context* c, int rank, int world) {
+    CTX(c);
+    if (world < 1 || rank < 0 || rank >= world) return fail(DR_ERR_INVALID, "bad shard %d/%d", rank, world);
+    if (rank != c->rank || world != c->world) { free_F(c); free_solver(c); }
+    c->rank = rank; c->world = world;
+    recompute_shard(c);
+    return DR_OK;
+}
+
+int dr_get_shard(dr_context* c, int* row0, int* nrows, int* rpr) {
+    CTX(c);
+    if (c->N <= 0) return fail(DR_ERR_STATE, "no mesh");
+    if (row0) *row0 = c->row0;
+    if (nrows) *nrows = c->nrows;
+    if (rpr) *rpr = c->rpr;
+    return DR_OK;
+}
+
+int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* normals, int Nn,
+                      const int32_t* tv, const int32_t* tn, int N) {
+    CTX(c);
+    if (!vertices || !normals || !tv || !tn) return fail(DR_ERR_INVALID, "null mesh array");
+    if (V <= 0 || Nn <= 0 || N <= 0) return fail(DR_ERR_INVALID, "empty mesh (V=%d Nn=%d N=%d)", V, Nn, N);
+    if ((size_t)N > (1u << 22)) return fail(DR_ERR_INVALID, "N=%d exceeds %u patches", N, 1u << 22);
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (size_t k = 0; k < (size_t)3 * N; k++) {
+        if (tv[k] < 0 || tv[k] >= V) return fail(DR_ERR_INVALID, "vertex index %d of triangle %zu out of range [0,%d)", tv[k], k / 3, V);
+        if (tn[k] < 0 || tn[k] >= Nn) return fail(DR_ERR_INVALID, "normal index %d of triangle %zu out of range [0,%d)", tn[k], k / 3, Nn);
+        const float* p = vertices + 3 * (size_t)tv[k];
+        for (int a = 0; a < 3; a++) {
+            if (!std::isfinite(p[a])) return fail(DR_ERR_INVALID, "non-finite vertex %d", tv[k]);
+            lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]);
+        }
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    free_solver(c); free_F(c); free_scene(c);
+    c->N = N; c->V = V; c->Nn = Nn;
+    HIPCHK(hipMalloc(&c->d_vtx, sizeof(float) * 3 * (size_t)V));
+    HIPCHK(hipMalloc(&c->d_nrm, sizeof(float) * 3 * (size_t)Nn));
+    HIPCHK(hipMalloc(&c->d_tv, sizeof(int) * 3 * (size_t)N));
+    HIPCHK(hipMalloc(&c->d_tn, sizeof(int) * 3 * (size_t)N));
+    HIPCHK(hipMalloc(&c->d_patch, sizeof(PatchRec) * (size_t)N));
+    HIPCHK(hipMalloc(&c->d_tri, sizeof(TriRec) * (size_t)N));
+    c->n_nodes = 2 * N - 1;
+    HIPCHK(hipMalloc(&c->d_bvh, sizeof(BvhNode) * (size_t)c->n_nodes));
+    HIPCHK(hipMemcpyAsync(c->d_vtx, vertices, sizeof(float) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_nrm, normals, sizeof(float) * 3 * (size_t)Nn, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_tv, tv, sizeof(int) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_tn, tn, sizeof(int) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_patch_records(c->stream, N, c->d_vtx, c->d_nrm, c->d_tv, c->d_tn, c->d_patch, c->d_tri));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, c->stream));
+    hipError_t be = build_lbvh(c->stream, N, c->d_tri, lo, hi, c->d_bvh);
+    if (be != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return fail(DR_ERR_DEVICE, "LBVH build failed: %s", hipGetErrorString(be)); }
+    HIPCHK(hipEventRecord(e1, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    c->last_bvh_ms = ms;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    recompute_shard(c);
+    return DR_OK;
+}
+
+static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int rule, int keep_vis, int trace) {
+    CTX(c);
+    if (c->N <= 0) return fail(DR_ERR_STATE, "dr_scene_set_mesh has not been called");
+    if (trace && (!uv || K < 1 || K > 254)) return fail(DR_ERR_INVALID, "need 1 <= K <= 254 samples (K=%d)", K);
+    if (rule != DR_RULE_INTEGRAND && rule != DR_RULE_RECIPROCITY) return fail(DR_ERR_INVALID, "unknown rule %d", rule);
+    int rc = ensure_F(c);
+    if (rc) return rc;
+    c->have_F = false;
+    if (c->ldF != (size_t)c->N) HIPCHK(hipMemsetAsync(c->d_F, 0, c->F_floats * sizeof(float), c->stream));
+    hipFree(c->d_vis); c->d_vis = nullptr;
+    if (keep_vis && c->nrows > 0) HIPCHK(hipMalloc(&c->d_vis, (size_t)c->nrows * c->N));
+    if (trace) {
+        hipFree(c->d_uv); c->d_uv = nullptr;
+        HIPCHK(hipMalloc(&c->d_uv, sizeof(float) * 2 * (size_t)K));
+        HIPCHK(hipMemcpyAsync(c->d_uv, uv, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, c->stream));
+    if (c->nrows > 0) {
+        TileParams p;
+        p.N = c->N; p.K = trace ? K : 1; p.rule = rule; p.trace = trace;
+        p.nT = (c->N + TILE - 1) / TILE; p.tile0 = c->row0 / TILE; p.nOwnedTiles = (c->nrows + TILE - 1) / TILE;
+        p.row0 = c->row0; p.nrows = c->nrows; p.n_nodes = c->n_nodes; p.eps = eps; p.ldF = c->ldF;
+        p.F = c->d_F; p.vis = c->d_vis; p.patch = c->d_patch; p.tri = c->d_tri; p.bvh = c->d_bvh;
+        p.uv = c->d_uv; p.pairs_traced = c->d_counter;
+        HIPCHK(launch_ff_tiles(c->stream, p));
+    }
+    HIPCHK(hipEventRecord(e1, c->stream));
+    HIPCHK(hipMemcpyAsync(&c->pairs_traced, c->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    c->last_assemble_ms = ms;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    c->have_F = true;
+    return DR_OK;
+}
+
+int dr_formfactors_assemble(dr_context* c, const float* uv, int K, float eps, int rule, int keep_vis) {
+    return assemble_impl(c, uv, K, eps, rule, keep_vis, 1);
+}
+int dr_formfactors_integrand_only(dr_context* c) {
+    return assemble_impl(c, nullptr, 1, 0.0f, DR_RULE_INTEGRAND, 0, 0);
+}
+
+static int check_rows(dr_context* c, int row0, int nrows) {
+    if (nrows < 0 || row0 < c->row0 || row0 + nrows > c->row0 + c->nrows)
+        return fail(DR_ERR_INVALID, "rows [%d,%d) not inside this rank's rows [%d,%d)", row0, row0 + nrows, c->row0, c->row0 + c->nrows);
+    return DR_OK;
+}
+
+int dr_formfactors_read_rows(dr_context* c, int row0, int nrows, float* out) {
+    CTX(c);
+    if (!c->have_F) return fail(DR_ERR_STATE, "form factors not assembled");
+    if (!out) return fail(DR_ERR_INVALID, "out is null");
+    int rc = check_rows(c, row0, nrows);
+    if (rc) return rc;
+    if (nrows == 0) return DR_OK;
+    HIPCHK(hipMemcpy2DAsync(out, sizeof(float) * c->N, c->d_F + (size_t)(row0 - c->row0) * c->ldF, sizeof(float) * c->ldF,
+                            sizeof(float) * c->N, nrows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DR_OK;
+}
+
+int dr_visibility_read_rows(dr_context* c, int row0, int nrows, uint8_t* out) {
+    CTX(c);
+    if (!c->have_F || !c->d_vis) return fail(DR_ERR_STATE, "visibility counts were not kept (keep_visibility = 0)");
+    if (!out) return fail(DR_ERR_INVALID, "out is null");
+    int rc = check_rows(c, row0, nrows);
+    if (rc) return rc;
+    if (nrows == 0) return DR_OK;
+    HIPCHK(hipMemcpyAsync(out, c->d_vis + (size_t)(row0 - c->row0) * c->N, (size_t)nrows * c->N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DR_OK;
+}
+
+int dr_formfactors_load_rows(dr_context* c, int row0, int nrows, const float* F) {
+    CTX(c);
+    if (c->N <= 0) return fail(DR_ERR_STATE, "dr_scene_set_mesh has not been called");
+    if (!F) return fail(DR_ERR_INVALID, "F is null");
+    int rc = check_rows(c, row0, nrows);
+    if (rc) return rc;
+    bool fresh = (c->d_F == nullptr);
+    rc = ensure_F(c);
+    if (rc) return rc;
+    if (fresh) HIPCHK(hipMemsetAsync(c->d_F, 0, c->F_floats * sizeof(float), c->stream));
+    if (nrows > 0)
+        HIPCHK(hipMemcpy2DAsync(c->d_F + (size_t)(row0 - c->row0) * c->ldF, sizeof(float) * c->ldF, F, sizeof(float) * c->N,
+                                sizeof(float) * c->N, nrows, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_F = true;
+    return DR_OK;
+}
+
+int dr_solver_init(dr_context* c, int S, const float* E, const float* M, int n_mat, const int32_t* mat_of_patch) {
+    CTX(c);
+    if (c->N <= 0) return fail(DR_ERR_STATE, "dr_scene_set_mesh has not been called");
+    if (S < 1 || S > DR_MAX_BINS) return fail(DR_ERR_INVALID, "S=%d outside 1..%d", S, DR_MAX_BINS);
+    if (!E || !M || !mat_of_patch || n_mat < 1) return fail(DR_ERR_INVALID, "null solver input");
+    for (int i = 0; i < c->N; i++)
+        if (mat_of_patch[i] < 0 || mat_of_patch[i] >= n_mat)
+            return fail(DR_ERR_INVALID, "material index %d of patch %d out of range [0,%d)", mat_of_patch[i], i, n_mat);
+    if (c->world > 1 && !c->comm.comm) return fail(DR_ERR_STATE, "world=%d but dr_comm_init has not been called", c->world);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    free_solver(c);
+    c->S = S; c->n_mat = n_mat;
+    const size_t full = (size_t)c->world * S * c->rpr;
+    HIPCHK(hipMalloc(&c->d_M, sizeof(float) * (size_t)n_mat * S * S));
+    HIPCHK(hipMalloc(&c->d_E, sizeof(float) * full));
+    HIPCHK(hipMalloc(&c->d_R[0], sizeof(float) * full));
+    HIPCHK(hipMalloc(&c->d_R[1], sizeof(float) * full));
+    HIPCHK(hipMalloc(&c->d_B, sizeof(float) * (size_t)S * c->rpr));
+    HIPCHK(hipMalloc(&c->d_mat, sizeof(int) * (size_t)c->rpr));
+    HIPCHK(hipMalloc(&c->d_sums, sizeof(double) * DR_MAX_BINS));
+    float* tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, sizeof(float) * (size_t)c->N * S));
+    HIPCHK(hipMemcpyAsync(tmp, E, sizeof(float) * (size_t)c->N * S, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_E, 0, sizeof(float) * full, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_R[0], 0, sizeof(float) * full, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_R[1], 0, sizeof(float) * full, c->stream));
+    HIPCHK(launch_scatter_rows(c->stream, tmp, c->N, S, c->rpr, c->world, c->d_E));
+    HIPCHK(hipMemcpyAsync(c->d_M, M, sizeof(float) * (size_t)n_mat * S * S, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_mat, 0, sizeof(int) * (size_t)c->rpr, c->stream));
+    if (c->nrows > 0)
+        HIPCHK(hipMemcpyAsync(c->d_mat, mat_of_patch + c->row0, sizeof(int) * (size_t)c->nrows, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipFree(tmp);
+    c->have_solver = true;
+    return dr_solver_reset(c);
+}
+
+int dr_solver_reset(dr_context* c) {
+    CTX(c);
+    if (!c->have_solver) return fail(DR_ERR_STATE, "dr_solver_init has not been called");
+    const size_t full = (size_t)c->world * c->S * c->rpr;
+    c->cur = 0;
+    HIPCHK(hipMemcpyAsync(c->d_R[0], c->d_E, sizeof(float) * full, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_B, c->d_E + (size_t)c->rank * c->S * c->rpr, sizeof(float) * (size_t)c->S * c->rpr,
+                          hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DR_OK;
+}
+
+int dr_solver_step(dr_context* c, int n_passes, float* residual_sum_out) {
+    CTX(c);
+    if (!c->have_solver) return fail(DR_ERR_STATE, "dr_solver_init has not been called");
+    if (!c->have_F) return fail(DR_ERR_STATE, "form factors not assembled");
+    if (n_passes < 0) return fail(DR_ERR_INVALID, "n_passes < 0");
+    for (int k = 0; k < n_passes; k++) {
+        int rc = sweep_once(c);
+        if (rc) return rc;
+    }
+    if (residual_sum_out) {
+        double sums[DR_MAX_BINS];
+        int rc = read_sums(c, sums);
+        if (rc) return rc;
+        double t = 0;
+        for (int s = 0; s < c->S; s++) t += sums[s];
+        *residual_sum_out = (float)t;
+    }
+    return DR_OK;
+}
+
+int dr_solver_residual_sums(dr_context* c, double* sums) {
+    CTX(c);
+    if (!c->have_solver) return fail(DR_ERR_STATE, "dr_solver_init has not been called");
+    if (!sums) return fail(DR_ERR_INVALID, "sums is null");
+    return read_sums(c, sums);
+}
+
+int dr_solver_converge(dr_context* c, float threshold, int per_bin, int max_iters, int* iters_out) {
+    CTX(c);
+    if (!c->have_solver) return fail(DR_ERR_STATE, "dr_solver_init has not been called");
+    if (!c->have_F) return fail(DR_ERR_STATE, "form factors not assembled");
+    if (max_iters < 0) return fail(DR_ERR_INVALID, "max_iters < 0");
+    int it = 0;
+    for (;;) {
+        double sums[DR_MAX_BINS];
+        int rc = read_sums(c, sums);
+        if (rc) return rc;
+        bool go = false;
+        if (per_bin) { for (int s = 0; s < c->S; s++) go = go || (sums[s] > (double)threshold); }
+        else { double t = 0; for (int s = 0; s < c->S; s++) t += sums[s]; go = t > (double)threshold; }
+        if (!go || it >= max_iters) break;
+        rc = sweep_once(c);
+        if (rc) return rc;
+        it++;
+    }
+    if (iters_out) *iters_out = it;
+    return DR_OK;
+}
+
+int dr_solver_read(dr_context* c, float* B, float* R) {
+    CTX(c);
+    if (!c->have_solver) return fail(DR_ERR_STATE, "dr_solver_init has not been called");
+    float* tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, sizeof(float) * (size_t)c->N * c->S));
+    if (R) {
+        HIPCHK(launch_gather_rows(c->stream, c->d_R[c->cur], c->N, c->S, c->rpr, c->world, tmp));
+        HIPCHK(hipMemcpyAsync(R, tmp, sizeof(float) * (size_t)c->N * c->S, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    if (B && c->nrows > 0) {
+        HIPCHK(launch_gather_rows(c->stream, c->d_B, c->nrows, c->S, c->rpr, 1, tmp));
+        HIPCHK(hipMemcpyAsync(B + (size_t)c->row0 * c->S, tmp, sizeof(float) * (size_t)c->nrows * c->S, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    hipFree(tmp);
+    return DR_OK;
+}
+
+int dr_comm_unique_id(void* out128) {
+    if (!out128) return fail(DR_ERR_INVALID, "out128 is null");
+    std::string e = comm_unique_id(out128);
+    if (!e.empty()) return fail(DR_ERR_COMM, "%s", e.c_str());
+    return DR_OK;
+}
+
+int dr_comm_init(dr_context* c, const void* id128, int rank, int world) {
+    CTX(c);
+    if (!id128) return fail(DR_ERR_INVALID, "id128 is null");
+    if (rank != c->rank || world != c->world) return fail(DR_ERR_INVALID, "comm %d/%d does not match shard %d/%d", rank, world, c->rank, c->world);
+    comm_destroy(c->comm);
+    std::string e = comm_init(c->comm, id128, rank, world);
+    if (!e.empty()) return fail(DR_ERR_COMM, "%s", e.c_str());
+    return DR_OK;
+}
+
+int dr_debug_read_bvh(dr_context* c, void* out, int max_nodes) {
+    CTX(c);
+    if (c->N <= 0) return fail(DR_ERR_STATE, "no mesh");
+    if (!out || max_nodes < c->n_nodes) return fail(DR_ERR_INVALID, "need room for %d nodes", c->n_nodes);
+    HIPCHK(hipMemcpyAsync(out, c->d_bvh, sizeof(BvhNode) * (size_t)c->n_nodes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DR_OK;
+}
+
+int dr_get_info(dr_context* c, dr_info* o) {
+    CTX(c);
+    if (!o) return fail(DR_ERR_INVALID, "out is null");
+    if (c->profile) { HIPCHK(hipStreamSynchronize(c->stream)); drain_events(c); }
+    memset(o, 0, sizeof *o);
+    o->N = c->N; o->S = c->S; o->rank = c->rank; o->world = c->world; o->row0 = c->row0; o->nrows = c->nrows;
+    o->rows_per_rank = c->rpr; o->n_bvh_nodes = c->n_nodes; o->ld_F = c->ldF; o->bytes_F = c->F_floats * sizeof(float);
+    o->last_assemble_ms = c->last_assemble_ms; o->last_bvh_ms = c->last_bvh_ms; o->pairs_traced = c->pairs_traced;
+    o->sweep_launches = c->sweep_launches; o->sweep_ms_total = c->sweep_ms_total;
+    return DR_OK;
+}
+
+int dr_profile_enable(dr_context* c, int on) {
+    CTX(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    drain_events(c);
+    c->profile = on != 0;
+    return DR_OK;
+}
+
+int dr_profile_reset(dr_context* c) {
+    CTX(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    drain_events(c);
+    c->sweep_launches = 0;
+    c->sweep_ms_total = 0;
+    return DR_OK;
+}
+
+int dr_synchronize(dr_context* c) {
+    CTX(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DR_OK;
+}
+
+}  // extern "C"

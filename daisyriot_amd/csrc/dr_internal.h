@@ -1,0 +1,80 @@
+// dr_internal.h -- shared between the C-ABI implementation and the HIP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace dr {
+
+// Per-patch quantities of the form-factor integrand, computed once per patch instead of
+// once per pair (vs/triangle_math.cpp:11-74 evaluated per patch).
+struct PatchRec {
+    float cen[4][3];   // centroids of the four midpoint sub-triangles
+    float nrm[3];      // normalised average of the three OBJ vertex normals
+    float sa[4];       // sub-triangle areas
+    float area;        // patch area
+};                      // 20 floats
+
+// a, e1 = b-a, e2 = c-a : uv2xyz (vs/triangle_math.cpp:3-9) and the ray/triangle test
+struct TriRec {
+    float a[3], e1[3], e2[3];
+    float pad[3];
+};                      // 12 floats = 48 B
+
+// Threaded BVH node in depth-first pre-order: the first child of an internal node is
+// node+1; `skip` is the pre-order index of the first node after this node's subtree.
+struct BvhNode {
+    float lo[3], hi[3];
+    int   skip;
+    int   tri;          // patch id for a leaf, -1 for an internal node
+};                      // 32 B: one s_load_dwordx8
+
+constexpr int TILE = 64;        // patch-pair tile edge of the assembly kernel
+constexpr int SHARD_ALIGN = 256; // rows per rank are a multiple of this (sweep column tile)
+
+struct TileParams {
+    int N, K, rule, trace, nT, tile0, nOwnedTiles, row0, nrows, n_nodes;
+    float eps;
+    size_t ldF;
+    float* F;                 // this rank's rows: F[(row-row0)*ldF + col]
+    unsigned char* vis;       // nullable, vis[(row-row0)*N + col]
+    const PatchRec* patch;
+    const TriRec* tri;
+    const BvhNode* bvh;
+    const float* uv;          // K x 2
+    unsigned long long* pairs_traced;
+};
+
+struct SweepParams {
+    int N;            // patches (columns with data)
+    int S;
+    int rpr;          // rows per rank (column-chunk size of the gathered residual)
+    int world;
+    int row0, nrows;  // this rank's rows
+    size_t ldF;
+    const float* F;
+    const float* Rin;     // [world][S][rpr]
+    float* Rout;          // [world][S][rpr]; this rank writes chunk `rank`
+    int rank;
+    float* B;             // [S][rpr] local
+    const float* M;       // [n_mat][S][S]
+    const int* mat;       // [rpr] local material index
+    int n_mat;
+};
+
+// launchers implemented in the .hip files
+hipError_t launch_patch_records(hipStream_t st, int N, const float* vtx, const float* nrm,
+                                const int* tv, const int* tn, PatchRec* patch, TriRec* tri);
+hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float scene_lo[3],
+                      const float scene_hi[3], BvhNode* nodes /* 2N-1 */);
+hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p);
+hipError_t launch_sweep(hipStream_t st, const SweepParams& p);
+hipError_t launch_colsums(hipStream_t st, const float* R, int world, int S, int rpr, double* sums);
+// layout conversion between the ABI's patch-major N x S and the device's bin-major chunks
+hipError_t launch_scatter_rows(hipStream_t st, const float* src_NxS, int N, int S, int rpr, int world,
+                               float* dst_chunks /* [world][S][rpr] */);
+hipError_t launch_gather_rows(hipStream_t st, const float* src_chunks, int N, int S, int rpr, int world,
+                              float* dst_NxS);
+
+}  // namespace dr

@@ -1,0 +1,508 @@
+// geom_kernels.hip -- per-patch records, on-device LBVH, and the fused form-factor tile
+// kernel (integrand + visibility + both F tiles written once) for gfx950.
+//
+// Compiled with -ffp-contract=off: every fp32 operation below is individually rounded, in
+// the written order, so that geometry decisions (which pairs are traced, which rays are
+// blocked) are bit-identical to the CPU oracle; divisions and square roots are the
+// correctly rounded ones (-fhip-fp32-correctly-rounded-divide-sqrt, hipcc's default).
+//
+// Reference behaviour restated here ("vs/" = "visual studio/"):
+//   integrand    vs/triangle_math.cpp:11-74, vs/OptixPrimeFunctionality.cpp:133-161,
+//                vs/parallellism.cu:91-151
+//   visibility   vs/OptixPrimeFunctionality.cpp:54-63, 169-218, 244-271 (closest hit must be
+//                the destination patch; OptiX Prime itself is replaced by the LBVH below)
+//   assembly     vs/OptixPrimeFunctionality.cpp:6-34 (both directions from the integrand) and
+//                :311-366 (reverse entry by reciprocity)
+#include "dr_internal.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+namespace dr {
+
+// ---------------------------------------------------------------------------------------
+// fp32 helpers in glm 0.9.8.4's operation order (func_geometric.inl)
+// ---------------------------------------------------------------------------------------
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 ld3(const float* p) { return f3{ p[0], p[1], p[2] }; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{ a.x + b.x, a.y + b.y, a.z + b.z }; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return f3{ a.x * s, a.y * s, a.z * s }; }
+__device__ __forceinline__ f3 div3(f3 a, float s) { return f3{ a.x / s, a.y / s, a.z / s }; }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ f3 cross3(f3 x, f3 y) {
+    return f3{ x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y };
+}
+__device__ __forceinline__ float len3(f3 a) { return sqrtf(dot3(a, a)); }
+__device__ __forceinline__ f3 normalize3(f3 a) { return a * (1.0f / sqrtf(dot3(a, a))); }
+// 0.5 (double) * length, truncated to float == 0.5f * length exactly
+__device__ __forceinline__ float surface3(f3 a, f3 b, f3 c) { return 0.5f * len3(cross3(b - a, c - a)); }
+__device__ __forceinline__ f3 centre3(f3 p0, f3 p1, f3 p2) {
+    f3 s = (p0 + p1) + p2;
+    return f3{ s.x / 3.0f, s.y / 3.0f, s.z / 3.0f };
+}
+
+#define DR_PIF 3.14159265358979323846f
+
+// ---------------------------------------------------------------------------------------
+// per-patch records
+// ---------------------------------------------------------------------------------------
+__global__ void k_patch_records(int N, const float* __restrict__ vtx, const float* __restrict__ nrm,
+                                const int* __restrict__ tv, const int* __restrict__ tn,
+                                PatchRec* __restrict__ patch, TriRec* __restrict__ tri) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    f3 a = ld3(vtx + 3 * (size_t)tv[3 * (size_t)t + 0]);
+    f3 b = ld3(vtx + 3 * (size_t)tv[3 * (size_t)t + 1]);
+    f3 c = ld3(vtx + 3 * (size_t)tv[3 * (size_t)t + 2]);
+    // midpoint split, vs/triangle_math.cpp:60-74
+    f3 iA = div3(b - a, 2.0f) + a;
+    f3 iC = div3(c - a, 2.0f) + a;
+    f3 iB = div3(b - c, 2.0f) + c;
+    f3 q[4][3] = { { a, iC, iA }, { iC, c, iB }, { iA, iB, b }, { iA, iB, iC } };
+    PatchRec r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        f3 ce = centre3(q[k][0], q[k][1], q[k][2]);
+        r.cen[k][0] = ce.x; r.cen[k][1] = ce.y; r.cen[k][2] = ce.z;
+        r.sa[k] = surface3(q[k][0], q[k][1], q[k][2]);
+    }
+    // averaged OBJ vertex normal, vs/triangle_math.cpp:23-29
+    f3 n0 = ld3(nrm + 3 * (size_t)tn[3 * (size_t)t + 0]);
+    f3 n1 = ld3(nrm + 3 * (size_t)tn[3 * (size_t)t + 1]);
+    f3 n2 = ld3(nrm + 3 * (size_t)tn[3 * (size_t)t + 2]);
+    f3 s = (n0 + n1) + n2;
+    f3 n = normalize3(f3{ s.x / 3.0f, s.y / 3.0f, s.z / 3.0f });
+    r.nrm[0] = n.x; r.nrm[1] = n.y; r.nrm[2] = n.z;
+    r.area = surface3(a, b, c);
+    patch[t] = r;
+    TriRec T;
+    f3 e1 = b - a, e2 = c - a;
+    T.a[0] = a.x; T.a[1] = a.y; T.a[2] = a.z;
+    T.e1[0] = e1.x; T.e1[1] = e1.y; T.e1[2] = e1.z;
+    T.e2[0] = e2.x; T.e2[1] = e2.y; T.e2[2] = e2.z;
+    T.pad[0] = b.x; T.pad[1] = b.y; T.pad[2] = b.z;   // b kept for exact leaf bounds
+    tri[t] = T;
+}
+
+hipError_t launch_patch_records(hipStream_t st, int N, const float* vtx, const float* nrm,
+                                const int* tv, const int* tn, PatchRec* patch, TriRec* tri) {
+    hipLaunchKernelGGL(k_patch_records, dim3((N + 255) / 256), dim3(256), 0, st, N, vtx, nrm, tv, tn, patch, tri);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// LBVH (Karras 2012): Morton keys -> radix sort -> hierarchy -> bottom-up bounds ->
+// pre-order threaded layout.  Replaces rtpModelUpdate (vs/OptixPrimeFunctionality.cpp:43-47).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long expand21(unsigned int v) {
+    unsigned long long x = v & 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__device__ __forceinline__ void tri_bounds(const TriRec& T, float lo[3], float hi[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float pa = T.a[a], pb = T.pad[a], pc = T.a[a] + T.e2[a];
+        // c itself is not stored; a+e2 is within one rounding of it and the boxes are padded
+        lo[a] = fminf(pa, fminf(pb, pc));
+        hi[a] = fmaxf(pa, fmaxf(pb, pc));
+    }
+}
+
+__global__ void k_morton(int N, const TriRec* __restrict__ tri, float3 slo, float3 sinv,
+                         unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    float lo[3], hi[3];
+    tri_bounds(tri[t], lo, hi);
+    float cx = (0.5f * (lo[0] + hi[0]) - slo.x) * sinv.x;
+    float cy = (0.5f * (lo[1] + hi[1]) - slo.y) * sinv.y;
+    float cz = (0.5f * (lo[2] + hi[2]) - slo.z) * sinv.z;
+    unsigned int ix = (unsigned int)fminf(fmaxf(cx * 2097152.0f, 0.0f), 2097151.0f);
+    unsigned int iy = (unsigned int)fminf(fmaxf(cy * 2097152.0f, 0.0f), 2097151.0f);
+    unsigned int iz = (unsigned int)fminf(fmaxf(cz * 2097152.0f, 0.0f), 2097151.0f);
+    keys[t] = (expand21(ix) << 2) | (expand21(iy) << 1) | expand21(iz);
+    vals[t] = t;
+}
+
+// common-prefix length of sorted keys i and j; index bits break ties between equal keys
+__device__ __forceinline__ int delta(const unsigned long long* keys, int N, int i, int j) {
+    if (j < 0 || j >= N) return -1;
+    unsigned long long a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((unsigned int)i ^ (unsigned int)j);
+    return __clzll(a ^ b);
+}
+
+// node ids: internal i in [0,N-1), leaf k -> N-1+k
+__global__ void k_hierarchy(int N, const unsigned long long* __restrict__ keys, int* __restrict__ left,
+                            int* __restrict__ right, int* __restrict__ first, int* __restrict__ last,
+                            int* __restrict__ parent) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N - 1) return;
+    int d = (delta(keys, N, i, i + 1) - delta(keys, N, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = delta(keys, N, i, i - d);
+    int lmax = 2;
+    while (delta(keys, N, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(keys, N, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = delta(keys, N, i, j);
+    int s = 0;
+    int t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(keys, N, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    int gamma = i + s * d + min(d, 0);
+    int lo = min(i, j), hi = max(i, j);
+    int lc = (lo == gamma) ? (N - 1 + gamma) : gamma;
+    int rc = (hi == gamma + 1) ? (N - 1 + gamma + 1) : (gamma + 1);
+    left[i] = lc; right[i] = rc; first[i] = lo; last[i] = hi;
+    parent[lc] = i; parent[rc] = i;
+    if (i == 0) parent[0] = -1;
+}
+
+__global__ void k_refit(int N, const TriRec* __restrict__ tri, const int* __restrict__ sorted_tri,
+                        const int* __restrict__ left, const int* __restrict__ right,
+                        const int* __restrict__ parent, int* __restrict__ flags,
+                        float* __restrict__ box /* (2N-1) x 6 */, float pad) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    float lo[3], hi[3];
+    tri_bounds(tri[sorted_tri[k]], lo, hi);
+    int id = N - 1 + k;
+    float* b = box + 6 * (size_t)id;
+    for (int a = 0; a < 3; a++) { lo[a] -= pad; hi[a] += pad; b[a] = lo[a]; b[3 + a] = hi[a]; }
+    int p = (N > 1) ? parent[id] : -1;
+    while (p >= 0) {
+        __threadfence();                       // publish this subtree's box (agent scope)
+        int old = atomicAdd(&flags[p], 1);
+        if (old == 0) return;                  // the sibling's thread continues upwards
+        __threadfence();                       // acquire the sibling's box
+        int sib = (left[p] == id) ? right[p] : left[p];
+        const volatile float* sb = box + 6 * (size_t)sib;
+        for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], sb[a]); hi[a] = fmaxf(hi[a], sb[3 + a]); }
+        float* pb = box + 6 * (size_t)p;
+        for (int a = 0; a < 3; a++) { pb[a] = lo[a]; pb[3 + a] = hi[a]; }
+        id = p;
+        p = parent[p];
+    }
+}
+
+__global__ void k_emit(int N, const int* __restrict__ sorted_tri, const int* __restrict__ left,
+                       const int* __restrict__ first, const int* __restrict__ last,
+                       const int* __restrict__ parent, const float* __restrict__ box,
+                       BvhNode* __restrict__ nodes) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 2 * N - 1) return;
+    int size = (id < N - 1) ? 2 * (last[id] - first[id]) + 1 : 1;
+    int idx = 0;
+    int cur = id;
+    while (cur != 0 && N > 1) {
+        int p = parent[cur];
+        if (left[p] == cur) idx += 1;
+        else {
+            int lc = left[p];
+            int lsize = (lc < N - 1) ? 2 * (last[lc] - first[lc]) + 1 : 1;
+            idx += 1 + lsize;
+        }
+        cur = p;
+    }
+    BvhNode nd;
+    const float* b = box + 6 * (size_t)id;
+    for (int a = 0; a < 3; a++) { nd.lo[a] = b[a]; nd.hi[a] = b[3 + a]; }
+    nd.skip = idx + size;
+    nd.tri = (id < N - 1) ? -1 : sorted_tri[id - (N - 1)];
+    nodes[idx] = nd;
+}
+
+hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[3], const float shi[3],
+                      BvhNode* nodes) {
+    hipError_t e;
+    unsigned long long *keys = nullptr, *keys2 = nullptr;
+    int *vals = nullptr, *vals2 = nullptr, *ibuf = nullptr;
+    float* box = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    const size_t nn = 2 * (size_t)N - 1;
+    float ext = fmaxf(shi[0] - slo[0], fmaxf(shi[1] - slo[1], shi[2] - slo[2]));
+    float pad = 1e-4f * ext + 1e-30f;
+    float3 lo3 = make_float3(slo[0], slo[1], slo[2]);
+    float3 inv3 = make_float3(shi[0] > slo[0] ? 1.0f / (shi[0] - slo[0]) : 0.0f,
+                              shi[1] > slo[1] ? 1.0f / (shi[1] - slo[1]) : 0.0f,
+                              shi[2] > slo[2] ? 1.0f / (shi[2] - slo[2]) : 0.0f);
+#define DR_TRY(x) do { e = (x); if (e != hipSuccess) goto done; } while (0)
+    DR_TRY(hipMalloc(&keys, sizeof(unsigned long long) * N));
+    DR_TRY(hipMalloc(&keys2, sizeof(unsigned long long) * N));
+    DR_TRY(hipMalloc(&vals, sizeof(int) * N));
+    DR_TRY(hipMalloc(&vals2, sizeof(int) * N));
+    // left,right,first,last,flags: N-1 each; parent: 2N-1
+    DR_TRY(hipMalloc(&ibuf, sizeof(int) * (5 * (size_t)N + nn)));
+    DR_TRY(hipMalloc(&box, sizeof(float) * 6 * nn));
+    {
+        int* left = ibuf; int* right = ibuf + N; int* first = ibuf + 2 * (size_t)N;
+        int* last = ibuf + 3 * (size_t)N; int* flags = ibuf + 4 * (size_t)N; int* parent = ibuf + 5 * (size_t)N;
+        const int nb = (N + 255) / 256;
+        hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, st, N, tri, lo3, inv3, keys, vals);
+        DR_TRY(hipGetLastError());
+        DR_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (unsigned int)N, 0, 64, st));
+        DR_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+        DR_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (unsigned int)N, 0, 64, st));
+        DR_TRY(hipMemsetAsync(flags, 0, sizeof(int) * N, st));
+        if (N > 1) {
+            hipLaunchKernelGGL(k_hierarchy, dim3(nb), dim3(256), 0, st, N, keys2, left, right, first, last, parent);
+            DR_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_refit, dim3(nb), dim3(256), 0, st, N, tri, vals2, left, right, parent, flags, box, pad);
+        DR_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_emit, dim3((int)((nn + 255) / 256)), dim3(256), 0, st, N, vals2, left, first, last, parent, box, nodes);
+        DR_TRY(hipGetLastError());
+        DR_TRY(hipStreamSynchronize(st));
+    }
+#undef DR_TRY
+done:
+    (void)hipFree(keys); (void)hipFree(keys2); (void)hipFree(vals); (void)hipFree(vals2);
+    (void)hipFree(ibuf); (void)hipFree(box); (void)hipFree(tmp);
+    return e;
+}
+
+// ---------------------------------------------------------------------------------------
+// ray / triangle and ray / box
+// ---------------------------------------------------------------------------------------
+// Two-sided Moller-Trumbore; a hit needs u>=0, v>=0, u+v<=1, t>0 (the reference accepts
+// hit.t > 0, vs/OptixPrimeFunctionality.cpp:208).  det == 0 yields inf/NaN, which fail.
+__device__ __forceinline__ bool tri_hit(f3 o, f3 d, f3 a, f3 e1, f3 e2, float& t_out) {
+    f3 p = cross3(d, e2);
+    float det = dot3(e1, p);
+    float inv = 1.0f / det;
+    f3 tv = o - a;
+    float u = dot3(tv, p) * inv;
+    f3 q = cross3(tv, e1);
+    float v = dot3(d, q) * inv;
+    float t = dot3(e2, q) * inv;
+    t_out = t;
+    return (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t > 0.0f);
+}
+
+// conservative slab test of the segment [0,tmax] against a (padded) box held in SGPRs
+__device__ __forceinline__ bool box_hit(const BvhNode& nd, f3 o, f3 inv, float tmax) {
+    float t0 = (nd.lo[0] - o.x) * inv.x, t1 = (nd.hi[0] - o.x) * inv.x;
+    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+    t0 = (nd.lo[1] - o.y) * inv.y; t1 = (nd.hi[1] - o.y) * inv.y;
+    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+    t0 = (nd.lo[2] - o.z) * inv.z; t1 = (nd.hi[2] - o.z) * inv.z;
+    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+    return (tn <= tf * 1.00001f) && (tf >= 0.0f) && (tn <= tmax);
+}
+
+__device__ __forceinline__ float safe_inv(float d) {
+    // a zero component must not turn (plane - origin) * inv into 0*inf = NaN
+    return d == 0.0f ? 3.0e38f : 1.0f / d;
+}
+
+// ---------------------------------------------------------------------------------------
+// fused tile kernel
+// ---------------------------------------------------------------------------------------
+constexpr int REC_STRIDE = 21;      // 20 floats + 1: conflict-free LDS rows
+constexpr int TA_STRIDE = TILE + 1;
+constexpr int VIS_STRIDE = TILE + 4;
+
+__device__ __forceinline__ float stored(float f) { return f > 0.0f ? f : 0.0f; }
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
+    const int t = blockIdx.x;
+    const int o = P.tile0 + blockIdx.y;
+    const bool t_owned = (t >= P.tile0) && (t < P.tile0 + P.nOwnedTiles);
+    if (t_owned && t < o) return;   // the unordered tile pair {t,o} belongs to block (x=o, y=t-tile0)
+    const int bi = min(t, o), bj = max(t, o);
+    const int I0 = bi * TILE, J0 = bj * TILE;
+    const bool diag = (bi == bj);
+    const bool ownI = (bi >= P.tile0) && (bi < P.tile0 + P.nOwnedTiles);
+    const bool ownJ = (bj >= P.tile0) && (bj < P.tile0 + P.nOwnedTiles);
+
+    __shared__ float sRec[2][TILE][REC_STRIDE];
+    __shared__ float sA[TILE][TA_STRIDE];     // stored integrand I->J
+    __shared__ float sB[TILE][TA_STRIDE];     // stored integrand J->I
+    __shared__ unsigned char sVis[TILE][VIS_STRIDE];
+    __shared__ unsigned short sQueue[TILE * TILE];
+    __shared__ int sCount;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+
+    if (tid == 0) sCount = 0;
+    for (int x = tid; x < 2 * TILE * 20; x += NT) {
+        int side = x / (TILE * 20);
+        int r = (x - side * TILE * 20) / 20, c = x % 20;
+        int g = (side ? J0 : I0) + r;
+        sRec[side][r][c] = (g < P.N) ? reinterpret_cast<const float*>(P.patch + g)[c] : 0.0f;
+    }
+    __syncthreads();
+
+    // ---- integrand for both directions of every pair of the tile ------------------------
+    for (int p = tid; p < TILE * TILE; p += NT) {
+        const int i = p >> 6, j = p & 63;
+        const int gi = I0 + i, gj = J0 + j;
+        const bool valid = (gi < P.N) && (gj < P.N) && (gi < gj);
+        float fa = 0.0f, fb = 0.0f;
+        if (valid) {
+            const float* ri = sRec[0][i];
+            const float* rj = sRec[1][j];
+            const f3 ni = f3{ ri[12], ri[13], ri[14] }, nj = f3{ rj[12], rj[13], rj[14] };
+            float ff[4][4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const f3 ci = f3{ ri[3 * s], ri[3 * s + 1], ri[3 * s + 2] };
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const f3 cj = f3{ rj[3 * u], rj[3 * u + 1], rj[3 * u + 2] };
+                    // vs/triangle_math.cpp:49-58 for origin (i,s), destination (j,u); the
+                    // reverse direction's term is bitwise the same value
+                    f3 d = cj - ci;
+                    float len = sqrtf(dot3(d, d));
+                    f3 dn = d * (1.0f / len);
+                    float c1 = dot3(ni, dn);
+                    float c2 = -dot3(nj, dn);
+                    float v = 0.0f;
+                    if (c1 > 0.0f && c2 > 0.0f) v = ((c1 * c2) / ((len * len) * DR_PIF)) * (ri[15 + s] * rj[15 + u]);
+                    ff[s][u] = v;
+                }
+            }
+            float accA = 0.0f, accB = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) accA = accA + ff[s][u];     // i's sub-triangles outer
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) accB = accB + ff[s][u];     // j's sub-triangles outer
+            fa = stored(accA / ri[19]);
+            fb = stored(accB / rj[19]);
+        }
+        sA[i][j] = fa;
+        sB[i][j] = fb;
+        sVis[i][j] = 255;
+        // pairs to trace: stored integrand lo->hi > 0 (vs/OptixPrimeFunctionality.cpp:190)
+        const bool act = valid && (fa > 0.0f);
+        const unsigned long long m = __ballot(act);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&sCount, __popcll(m));
+        base = __shfl(base, 0);
+        if (act) sQueue[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
+    }
+    __syncthreads();
+    const int n_act = sCount;
+
+    // ---- visibility: one wave per pair, one lane per ray, wave-uniform BVH walk ---------
+    if (n_act > 0 && P.trace) {
+        // queue entries are dealt round-robin to the block's waves (all indices wave-uniform)
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int n_act_u = __builtin_amdgcn_readfirstlane(n_act);
+        for (int q = wave; q < n_act_u; q += NT / 64) {
+            const int p = __builtin_amdgcn_readfirstlane((int)sQueue[q]);
+            const int i = p >> 6, j = p & 63;
+            const int lo = I0 + i, hi = J0 + j;
+            const TriRec Tl = P.tri[lo];
+            const TriRec Th = P.tri[hi];
+            const f3 la = ld3(Tl.a), le1 = ld3(Tl.e1), le2 = ld3(Tl.e2);
+            const f3 ha = ld3(Th.a), he1 = ld3(Th.e1), he2 = ld3(Th.e2);
+            int count = 0;
+            for (int k0 = 0; k0 < P.K; k0 += 64) {
+                const int k = k0 + lane;
+                bool alive = k < P.K;
+                f3 org = f3{ 0, 0, 0 }, dn = f3{ 0, 0, 1 };
+                float tmax = 0.0f;
+                if (alive) {
+                    const float u = P.uv[2 * k], v = P.uv[2 * k + 1];
+                    // uv2xyz on both patches, vs/triangle_math.cpp:3-9; ray per
+                    // vs/OptixPrimeFunctionality.cpp:191-196
+                    f3 src = (la + le1 * u) + le2 * v;
+                    f3 dst = (ha + he1 * u) + he2 * v;
+                    f3 dv = dst - src;
+                    dn = dv * (1.0f / sqrtf(dot3(dv, dv)));
+                    org = src + dn * P.eps;
+                    alive = tri_hit(org, dn, ha, he1, he2, tmax);   // the destination must be hit at all
+                }
+                const f3 inv = f3{ safe_inv(dn.x), safe_inv(dn.y), safe_inv(dn.z) };
+                int node = 0;
+                // every step moves forward in pre-order, so n_nodes steps bound the walk even
+                // if the node array were corrupt (no wave may spin forever on the device)
+                for (int guard = 0; guard < P.n_nodes && node < P.n_nodes; guard++) {
+                    if (__ballot(alive) == 0ull) break;
+                    const BvhNode nd = P.bvh[node];
+                    const bool hb = alive && box_hit(nd, org, inv, tmax);
+                    if (__ballot(hb) == 0ull) { node = __builtin_amdgcn_readfirstlane(nd.skip); continue; }
+                    const int tk = __builtin_amdgcn_readfirstlane(nd.tri);
+                    if (tk >= 0 && tk != hi) {
+                        const TriRec Tk = P.tri[tk];
+                        float tt;
+                        if (hb && tri_hit(org, dn, ld3(Tk.a), ld3(Tk.e1), ld3(Tk.e2), tt)) {
+                            // closest hit is not `hi`: something nearer, or an equal-t hit of lower id
+                            if (tt < tmax || (tt == tmax && tk < hi)) alive = false;
+                        }
+                    }
+                    node = node + 1;
+                }
+                count += __popcll(__ballot(alive));
+            }
+            if (lane == 0) sVis[i][j] = (unsigned char)count;
+        }
+    }
+    __syncthreads();
+
+    if (tid == 0 && n_act > 0 && P.trace && P.pairs_traced) atomicAdd(P.pairs_traced, (unsigned long long)n_act);
+
+    // ---- write both F tiles once, coalesced ---------------------------------------------
+    const float Kf = (float)P.K;
+    for (int pass = 0; pass < 2; pass++) {
+        // pass 0: rows of the I block (F[I0+r][J0+c]); pass 1: rows of the J block (F[J0+r][I0+c])
+        if (pass == 0 ? !ownI : (!ownJ || diag)) continue;
+        const int R0 = pass == 0 ? I0 : J0, C0 = pass == 0 ? J0 : I0;
+        for (int p = tid; p < TILE * TILE; p += NT) {
+            const int r = p >> 6, c = p & 63;
+            const int gr = R0 + r, gc = C0 + c;
+            if (gr >= P.N || gc >= P.N) continue;
+            // (i,j) = tile coordinates of the unordered pair, i in the I block
+            int i, j; bool fwd;     // fwd: the entry is F[lo][hi]
+            if (diag) { fwd = gr < gc; i = fwd ? r : c; j = fwd ? c : r; }
+            else { fwd = (pass == 0); i = fwd ? r : c; j = fwd ? c : r; }
+            float val = 0.0f;
+            unsigned char vc = 255;
+            if (gr != gc) {
+                vc = sVis[i][j];
+                const float fu_f = sA[i][j], fu_r = sB[i][j];
+                if (fu_f > 0.0f) {
+                    const float V = P.trace ? (float)vc / Kf : 1.0f;
+                    if (!P.trace) vc = 255;
+                    if (P.rule == 0) {
+                        if (V > 0.0f) val = V * (fwd ? fu_f : fu_r);
+                    } else {
+                        const float f = fu_f * V;
+                        if (f > 0.0f) val = fwd ? f : (sRec[0][i][19] * f) / sRec[1][j][19];
+                    }
+                }
+            }
+            P.F[(size_t)(gr - P.row0) * P.ldF + gc] = val;
+            if (P.vis) P.vis[(size_t)(gr - P.row0) * P.N + gc] = vc;
+        }
+    }
+}
+
+hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p) {
+    constexpr int NT = 512;
+    dim3 grid(p.nT, p.nOwnedTiles);
+    hipLaunchKernelGGL(k_ff_tiles<NT>, grid, dim3(NT), 0, st, p);
+    return hipGetLastError();
+}
+
+}  // namespace dr

@@ -1,0 +1,160 @@
+/*
+ * daisyriot_hip.h -- C ABI of libdaisyriot_hip.so: DaisyRiot's radiosity hot
+ * path (form-factor assembly + per-bin light-pass iteration) on one MI355X.
+ *
+ * One context drives one GPU (one process per GPU).  Row-sharded multi-GPU
+ * runs create one context per rank, all with the same mesh, and call
+ * dr_set_shard + dr_comm_init; the only data-path collective is the
+ * all-gather of the residual vector after each pass.
+ *
+ * Each entry point names the reference interface it replaces ("vs/" =
+ * "visual studio/" in asylunatic/DaisyRiot).  No C++ or torch types cross
+ * this boundary: plain pointers and sizes.  Host pointers are read/written
+ * during the call only and never retained.  All calls are synchronous at the
+ * ABI unless stated; a context is not thread-safe.
+ *
+ * Every function returns DR_OK (0) or a negative dr_status; the message of
+ * the last failure on the calling thread is dr_last_error().
+ */
+#ifndef DAISYRIOT_HIP_H
+#define DAISYRIOT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dr_context dr_context;
+
+typedef enum {
+    DR_OK = 0,
+    DR_ERR_INVALID = -1,   /* bad argument / index out of range / wrong call order */
+    DR_ERR_DEVICE = -2,    /* a HIP call failed (reference: cudaCheckError prints and continues, vs/parallellism.cuh:21-26) */
+    DR_ERR_NOMEM = -3,     /* device allocation failed (e.g. N*N*4 does not fit) */
+    DR_ERR_COMM = -4,      /* RCCL missing or a collective failed */
+    DR_ERR_STATE = -5      /* required earlier step missing (mesh / F / solver) */
+} dr_status;
+
+/* which rule produces the reverse entry F[col][row] of a traced pair row<col */
+typedef enum {
+    /* vs/OptixPrimeFunctionality.cpp:6-34 + 169-218 (ini cuda_on = true): both
+     * directions from the integrand, one shared visibility fraction */
+    DR_RULE_INTEGRAND = 0,
+    /* vs/OptixPrimeFunctionality.cpp:311-366 (cuda_on = false): reverse entry by
+     * reciprocity A_row*F/A_col */
+    DR_RULE_RECIPROCITY = 1
+} dr_rule;
+
+#define DR_MAX_BINS 16            /* S, spectral bins per patch */
+#define DR_RAYS_PER_PATCH 50      /* vs/Defines.h:25 */
+#define DR_ORIGIN_EPS 0.000001f   /* vs/OptixPrimeFunctionality.cpp:194 */
+
+const char* dr_last_error(void);
+
+/* ---- context ------------------------------------------------------------------ */
+/* Replaces the OptiX Prime context + CUDA runtime set-up
+ * (vs/OptixPrimeFunctionality.cpp:36-37).  device_id = HIP ordinal. */
+int dr_context_create(int device_id, dr_context** out);
+int dr_context_destroy(dr_context* ctx);
+
+/* Use the caller's hipStream_t for every launch and copy (NULL = the
+ * context's own stream).  Lets a host that already owns streams
+ * (torch.cuda.current_stream().cuda_stream) order its work with ours. */
+int dr_set_stream(dr_context* ctx, void* hip_stream);
+
+/* Row sharding: this context owns rows [rank*rpr, min(N,(rank+1)*rpr)) of F,
+ * rpr = ceil(N/world) rounded up to a multiple of 256.  Call before
+ * dr_formfactors_assemble.  Default rank 0 / world 1 (all rows). */
+int dr_set_shard(dr_context* ctx, int rank, int world);
+int dr_get_shard(dr_context* ctx, int* row0, int* nrows, int* rows_per_rank);
+
+/* ---- scene --------------------------------------------------------------------- */
+/* Exactly the MeshS / SimpleMesh arrays (vs/MeshS.h:14-20, vs/Defines.h:14-23;
+ * handed over today at vs/OptixPrimeFunctionality.cpp:13 and :38-44):
+ * vertices 3*V, normals 3*Nn, per-triangle vertex and normal indices 3*N,
+ * 0-based.  Builds the per-patch records and the on-device LBVH (replaces
+ * rtpModelUpdate, vs/OptixPrimeFunctionality.cpp:43-47). */
+int dr_scene_set_mesh(dr_context* ctx, const float* vertices, int V,
+                      const float* normals, int Nn,
+                      const int32_t* tri_vertex_idx,
+                      const int32_t* tri_normal_idx, int N);
+
+/* ---- form factors ---------------------------------------------------------------- */
+/* Replaces OptixPrimeFunctionality::cudaCalculateRadiosityMatrix /
+ * calculateRadiosityMatrix (vs/OptixPrimeFunctionality.cpp:6, :311) together
+ * with parallellism::runCalculateRadiosityMatrix (vs/parallellism.cu:4) and
+ * calculateAllVisibility (:169).  uv = K (u,v) samples (the reference's
+ * `rands`, :54-63; K = RAYS_PER_PATCH), 1 <= K <= 254.  The dense fp32 matrix
+ * stays resident on the device (this rank's rows).  keep_visibility != 0 also
+ * keeps the per-pair ray counts (tests; N*nrows bytes). */
+int dr_formfactors_assemble(dr_context* ctx, const float* uv, int K,
+                            float origin_eps, int rule, int keep_visibility);
+
+/* Unoccluded integrand only (parallellism::calculateRow, vs/parallellism.cu:91-111):
+ * F = stored integrand, no rays.  For tests and timing of the integrand alone. */
+int dr_formfactors_integrand_only(dr_context* ctx);
+
+/* Copy rows [row0,row0+nrows) (must be owned) to out[nrows*N] row-major.
+ * out[r*N+c] = F(row0+r -> c), the RadMat(i,j) of vs/Lightning.h:19. */
+int dr_formfactors_read_rows(dr_context* ctx, int row0, int nrows, float* out);
+/* ray counts 0..K per entry, 255 = pair not traced; needs keep_visibility */
+int dr_visibility_read_rows(dr_context* ctx, int row0, int nrows, uint8_t* out);
+/* Upload externally produced rows (the DeserializeMat route, vs/Lightning.h:51-74,
+ * and sweep-only tests).  Allocates F on first use. */
+int dr_formfactors_load_rows(dr_context* ctx, int row0, int nrows, const float* F);
+
+/* ---- solver ---------------------------------------------------------------------- */
+/* Replaces the Lightning constructors' set-up (vs/Lightning.h:114-139, 317-330,
+ * 393-404): S bins; E[N*S] patch-major emission (R0 = B0 = E, reset());
+ * M[n_mat*S*S] row-major per-material bin-transfer matrices (spectral:
+ * Material::M; RGB: diag(Kd); BW: S=1, M=[1]); mat_of_patch[N]. */
+int dr_solver_init(dr_context* ctx, int S, const float* E, const float* M,
+                   int n_mat, const int32_t* mat_of_patch);
+/* n_passes of increment_lightpass (vs/Lightning.h:196-226, 342-349, 419-424):
+ * R <- M_mat(i) * (F*R)[i], B += R; all S bins per pass, F streamed once.
+ * residual_sum_out (nullable) = sum over patches and bins of R after the last pass. */
+int dr_solver_step(dr_context* ctx, int n_passes, float* residual_sum_out);
+/* converge_lightning (vs/Lightning.h:145-151: total sum > threshold;
+ * per_bin != 0 = the RGB rule :336-340, any bin sum > threshold).  Stops after
+ * max_iters passes at the latest (the reference has no cap and BW never
+ * terminates in closed scenes). */
+int dr_solver_converge(dr_context* ctx, float threshold, int per_bin,
+                       int max_iters, int* iters_out);
+/* reset() (vs/Lightning.h:159-165): R = B = E */
+int dr_solver_reset(dr_context* ctx);
+/* B (lightningvalues) and R (residualvector), N*S patch-major, either nullable.
+ * B holds this rank's rows only; rows of other ranks are left untouched. */
+int dr_solver_read(dr_context* ctx, float* B, float* R);
+int dr_solver_residual_sums(dr_context* ctx, double* sums /* S */);
+
+/* ---- multi-GPU exchange (no reference counterpart: the reference is single-GPU) ---- */
+/* 128-byte RCCL unique id made on rank 0 and handed to every rank by the host. */
+int dr_comm_unique_id(void* out128);
+int dr_comm_init(dr_context* ctx, const void* id128, int rank, int world);
+
+/* ---- measurement ----------------------------------------------------------------- */
+typedef struct {
+    int    N, S, rank, world, row0, nrows, rows_per_rank, n_bvh_nodes;
+    size_t ld_F;              /* leading dimension of F in floats */
+    size_t bytes_F;           /* resident bytes of the F shard */
+    double last_assemble_ms;  /* hipEvent time of the last assemble (BVH + tiles) */
+    double last_bvh_ms;
+    uint64_t pairs_traced;    /* unordered pairs traced by the last assemble */
+    uint64_t sweep_launches;  /* profiled sweep launches since dr_profile_reset */
+    double sweep_ms_total;    /* their summed hipEvent durations */
+} dr_info;
+int dr_get_info(dr_context* ctx, dr_info* out);
+/* record a hipEvent pair around every sweep kernel launch (on its own stream) */
+int dr_profile_enable(dr_context* ctx, int on);
+int dr_profile_reset(dr_context* ctx);
+int dr_synchronize(dr_context* ctx);
+/* tests: the threaded LBVH, n_bvh_nodes records of 32 bytes
+ * {float lo[3], hi[3]; int32 skip; int32 patch (-1 = internal)} in pre-order */
+int dr_debug_read_bvh(dr_context* ctx, void* out, int max_nodes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
