@@ -61,6 +61,7 @@ struct SweepParams {
     const float* M;       // [n_mat][S][S]
     const int* mat;       // [rpr] local material index
     int n_mat;
+    int skew;         // per-block start-tile multiplier (0 = every block starts at column 0)
 };
 
 // launchers implemented in the .hip files

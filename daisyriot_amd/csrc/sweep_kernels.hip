@@ -10,29 +10,32 @@
 // inside a chunk so a column tile of one bin is contiguous); B as [S][rpr].
 #include "dr_internal.h"
 
+#include <cstdlib>
+
 namespace dr {
 
-constexpr int TC = 256;   // columns per tile: 64 lanes x float4
+typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int S, int RR, int NW>
-__global__ __launch_bounds__(NW * 64) void k_sweep(SweepParams P) {
+// S bins, RR rows per wave, NW waves per block, CPL float4 column groups per lane per row
+// and tile (tile = 256*CPL columns), NT = non-temporal F loads (F is streamed once; keep
+// the residual, which every block re-reads, resident in L2 instead).
+template <int S, int RR, int NW, int CPL, bool NT, int OCC>
+__global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
+    constexpr int TC = 256 * CPL;
     __shared__ __attribute__((aligned(16))) float sR[2][S][TC];
     __shared__ float sG[NW][RR][S];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int rbase = (blockIdx.x * NW + wave) * RR;       // first local row of this wave
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rbase = (blockIdx.x * NW + wave) * RR;       // first local row of this wave (uniform)
     const int ntiles = (P.world * P.rpr) / TC;
     const int tiles_per_chunk = P.rpr / TC;
 
-    // rows past the shard are clamped for loading and masked at the end
+    // wave-uniform row bases (SGPRs); rows past the shard are clamped for loading, masked at the end
     const float* frow[RR];
 #pragma unroll
-    for (int r = 0; r < RR; r++) {
-        int row = min(rbase + r, P.nrows - 1);
-        frow[r] = P.F + (size_t)row * P.ldF + lane * 4;
-    }
+    for (int r = 0; r < RR; r++) frow[r] = P.F + (size_t)min(rbase + r, P.nrows - 1) * P.ldF;
 
     float acc[RR][S];
 #pragma unroll
@@ -40,62 +43,79 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepParams P) {
 #pragma unroll
         for (int s = 0; s < S; s++) acc[r][s] = 0.0f;
 
-    // cooperative staging of one residual tile: S*TC floats = S*64 float4
-    constexpr int R4_PER_THREAD = (S * 64 + NW * 64 - 1) / (NW * 64);
-    float4 rreg[R4_PER_THREAD];
+    // cooperative staging of one residual tile: S*TC floats = S*64*CPL float4
+    constexpr int NV4 = S * 64 * CPL;
+    constexpr int R4_PER_THREAD = (NV4 + NW * 64 - 1) / (NW * 64);
+    v4f rreg[R4_PER_THREAD];
     auto load_rtile = [&](int t) {
         const int chunk = t / tiles_per_chunk;
         const int l0 = (t - chunk * tiles_per_chunk) * TC;
+        const float* base = P.Rin + (size_t)chunk * S * P.rpr + l0;
 #pragma unroll
         for (int x = 0; x < R4_PER_THREAD; x++) {
-            int q = tid + x * NW * 64;        // float4 index inside the tile: s = q/64, c4 = q%64
-            if (q < S * 64) {
-                int s = q >> 6, c4 = q & 63;
-                rreg[x] = *reinterpret_cast<const float4*>(P.Rin + ((size_t)chunk * S + s) * P.rpr + l0 + c4 * 4);
+            const int q = tid + x * NW * 64;        // float4 index inside the tile
+            if (NV4 % (NW * 64) == 0 || q < NV4) {
+                const int s = q / (64 * CPL), c4 = q % (64 * CPL);
+                rreg[x] = *reinterpret_cast<const v4f*>(base + (size_t)s * P.rpr + c4 * 4);
             }
         }
     };
     auto store_rtile = [&](int buf) {
 #pragma unroll
         for (int x = 0; x < R4_PER_THREAD; x++) {
-            int q = tid + x * NW * 64;
-            if (q < S * 64) {
-                int s = q >> 6, c4 = q & 63;
-                *reinterpret_cast<float4*>(&sR[buf][s][c4 * 4]) = rreg[x];
+            const int q = tid + x * NW * 64;
+            if (NV4 % (NW * 64) == 0 || q < NV4) {
+                const int s = q / (64 * CPL), c4 = q % (64 * CPL);
+                *reinterpret_cast<v4f*>(&sR[buf][s][c4 * 4]) = rreg[x];
             }
         }
     };
-
-    float4 fcur[RR], fnext[RR];
-    load_rtile(0);
+    auto load_f = [&](int t, v4f (&dst)[RR][CPL]) {
 #pragma unroll
-    for (int r = 0; r < RR; r++) fcur[r] = *reinterpret_cast<const float4*>(frow[r]);
+        for (int r = 0; r < RR; r++)
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const v4f* p = reinterpret_cast<const v4f*>(frow[r] + (size_t)t * TC + c * 256 + lane * 4);
+                dst[r][c] = NT ? __builtin_nontemporal_load(p) : *p;
+            }
+    };
+
+    // Blocks start at different column tiles and wrap around: rows are a power-of-two
+    // stride apart, so lock-stepped blocks would otherwise hit the same HBM channels together.
+    int tt = (int)(((unsigned)blockIdx.x * (unsigned)P.skew) % (unsigned)ntiles);
+    v4f fcur[RR][CPL], fnext[RR][CPL];
+    load_rtile(tt);
+    load_f(tt, fcur);
     store_rtile(0);
     __syncthreads();
 
     for (int t = 0; t < ntiles; t++) {
         const bool more = (t + 1) < ntiles;
+        tt = (tt + 1 == ntiles) ? 0 : tt + 1;
         if (more) {
-#pragma unroll
-            for (int r = 0; r < RR; r++) fnext[r] = *reinterpret_cast<const float4*>(frow[r] + (size_t)(t + 1) * TC);
-            load_rtile(t + 1);
+            load_f(tt, fnext);
+            load_rtile(tt);
         }
         const int buf = t & 1;
 #pragma unroll
-        for (int s = 0; s < S; s++) {
-            const float4 x = *reinterpret_cast<const float4*>(&sR[buf][s][lane * 4]);
+        for (int c = 0; c < CPL; c++)
 #pragma unroll
-            for (int r = 0; r < RR; r++) {
-                acc[r][s] = fmaf(fcur[r].x, x.x, acc[r][s]);
-                acc[r][s] = fmaf(fcur[r].y, x.y, acc[r][s]);
-                acc[r][s] = fmaf(fcur[r].z, x.z, acc[r][s]);
-                acc[r][s] = fmaf(fcur[r].w, x.w, acc[r][s]);
+            for (int s = 0; s < S; s++) {
+                const v4f x = *reinterpret_cast<const v4f*>(&sR[buf][s][c * 256 + lane * 4]);
+#pragma unroll
+                for (int r = 0; r < RR; r++) {
+                    acc[r][s] = fmaf(fcur[r][c].x, x.x, acc[r][s]);
+                    acc[r][s] = fmaf(fcur[r][c].y, x.y, acc[r][s]);
+                    acc[r][s] = fmaf(fcur[r][c].z, x.z, acc[r][s]);
+                    acc[r][s] = fmaf(fcur[r][c].w, x.w, acc[r][s]);
+                }
             }
-        }
         if (more) store_rtile(buf ^ 1);
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < RR; r++) fcur[r] = fnext[r];
+        for (int r = 0; r < RR; r++)
+#pragma unroll
+            for (int c = 0; c < CPL; c++) fcur[r][c] = fnext[r][c];
     }
 
     // wave reduction of the RR*S partial sums
@@ -132,18 +152,55 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepParams P) {
     }
 }
 
-template <int S>
-static hipError_t launch_sweep_s(hipStream_t st, const SweepParams& p) {
-    constexpr int RR = (S <= 8) ? 8 : 4;
-    constexpr int NW = 4;
+template <int S, int RR, int NW, int CPL, bool NT, int OCC = 1>
+static hipError_t launch_cfg(hipStream_t st, const SweepParams& p) {
     const int rows_per_block = RR * NW;
     dim3 grid((p.nrows + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL((k_sweep<S, RR, NW>), grid, dim3(NW * 64), 0, st, p);
+    hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC>), grid, dim3(NW * 64), 0, st, p);
     return hipGetLastError();
 }
 
-hipError_t launch_sweep(hipStream_t st, const SweepParams& p) {
-    if (p.nrows <= 0) return hipSuccess;
+template <int S>
+static hipError_t launch_sweep_s(hipStream_t st, const SweepParams& p) {
+    // 8 rows per wave (4 above 8 bins: the accumulators are RR*S registers), 4 waves per block,
+    // non-temporal F loads: measured best on MI355X (profiles/r01/sweep_variants.md)
+    constexpr int RR = (S <= 8) ? 8 : 4;
+    return launch_cfg<S, RR, 4, 1, true>(st, p);
+}
+
+static int sweep_cfg() {
+    static int cfg = -1;
+    if (cfg < 0) { const char* e = getenv("DR_SWEEP_CFG"); cfg = e ? atoi(e) : 0; }
+    return cfg;
+}
+
+hipError_t launch_sweep(hipStream_t st, const SweepParams& p_in) {
+    if (p_in.nrows <= 0) return hipSuccess;
+    SweepParams p = p_in;
+    static int skew = -1;
+    if (skew < 0) { const char* e = getenv("DR_SWEEP_SKEW"); skew = e ? atoi(e) : 37; }
+    p.skew = skew;
+    if (p.rpr % 1024 == 0 && p.S == 8) {       // tuning variants (DR_SWEEP_CFG)
+        switch (sweep_cfg()) {
+            case 1: return launch_cfg<8, 8, 4, 1, false>(st, p);
+            case 2: return launch_cfg<8, 4, 8, 1, false>(st, p);
+            case 3: return launch_cfg<8, 4, 8, 2, false>(st, p);
+            case 4: return launch_cfg<8, 4, 4, 2, false>(st, p);
+            case 5: return launch_cfg<8, 2, 8, 4, false>(st, p);
+            case 6: return launch_cfg<8, 4, 8, 2, true>(st, p);
+            case 7: return launch_cfg<8, 4, 16, 1, false>(st, p);
+            case 8: return launch_cfg<8, 8, 8, 1, false>(st, p);
+            case 9: return launch_cfg<8, 8, 4, 1, false, 3>(st, p);
+            case 10: return launch_cfg<8, 8, 4, 1, false, 4>(st, p);
+            case 11: return launch_cfg<8, 4, 8, 1, false, 6>(st, p);
+            case 12: return launch_cfg<8, 4, 4, 1, false, 5>(st, p);
+            case 13: return launch_cfg<8, 4, 4, 2, false, 4>(st, p);
+            case 14: return launch_cfg<8, 4, 8, 1, true, 4>(st, p);
+            case 15: return launch_cfg<8, 2, 8, 2, false, 6>(st, p);
+            case 16: return launch_cfg<8, 4, 4, 1, true, 5>(st, p);
+            default: break;
+        }
+    }
     switch (p.S) {
 #define DR_CASE(n) case n: return launch_sweep_s<n>(st, p);
         DR_CASE(1) DR_CASE(2) DR_CASE(3) DR_CASE(4) DR_CASE(5) DR_CASE(6) DR_CASE(7) DR_CASE(8)
