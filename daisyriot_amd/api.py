@@ -24,7 +24,7 @@ EXPORTS = [
     "dr_formfactors_read_rows", "dr_visibility_read_rows", "dr_formfactors_load_rows", "dr_solver_init",
     "dr_solver_step", "dr_solver_converge", "dr_solver_reset", "dr_solver_read", "dr_solver_residual_sums",
     "dr_comm_unique_id", "dr_comm_init", "dr_get_info", "dr_profile_enable", "dr_profile_reset",
-    "dr_synchronize", "dr_debug_read_bvh",
+    "dr_synchronize", "dr_debug_read_bvh", "dr_shard_rows", "dr_residual_offset",
 ]
 
 
@@ -79,9 +79,12 @@ def load_library(path=None):
     L.dr_profile_reset.argtypes = [vp]
     L.dr_synchronize.argtypes = [vp]
     L.dr_debug_read_bvh.argtypes = [vp, vp, i]
+    L.dr_shard_rows.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    L.dr_residual_offset.argtypes = [i, i, i, i]
     for name in EXPORTS:
-        if name != "dr_last_error":
+        if name not in ("dr_last_error", "dr_residual_offset"):
             getattr(L, name).restype = i
+    L.dr_residual_offset.restype = C.c_size_t
     _lib = L
     return L
 
@@ -96,6 +99,19 @@ def _f32(a):
 
 def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def shard_rows(N, rank, world):
+    """(row0, nrows, rows_per_rank) of rank `rank` -- pure host arithmetic of the library."""
+    L = load_library()
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    if L.dr_shard_rows(int(N), int(rank), int(world), C.byref(a), C.byref(b), C.byref(c)):
+        raise DaisyRiotError("dr_shard_rows: %s" % L.dr_last_error().decode())
+    return a.value, b.value, c.value
+
+
+def residual_offset(i, s, S, rows_per_rank):
+    return int(load_library().dr_residual_offset(int(i), int(s), int(S), int(rows_per_rank)))
 
 
 def comm_unique_id():

@@ -98,12 +98,16 @@ void free_scene(dr_context* c) {
     c->d_patch = nullptr; c->d_tri = nullptr; c->d_bvh = nullptr; c->N = 0;
 }
 
+void shard_rows(int N, int rank, int world, int* row0, int* nrows, int* rpr) {
+    int per = (N + world - 1) / world;
+    *rpr = ((per + SHARD_ALIGN - 1) / SHARD_ALIGN) * SHARD_ALIGN;
+    *row0 = rank * *rpr;
+    *nrows = std::max(0, std::min(N - *row0, *rpr));
+}
+
 void recompute_shard(dr_context* c) {
     if (c->N <= 0) return;
-    int per = (c->N + c->world - 1) / c->world;
-    c->rpr = ((per + SHARD_ALIGN - 1) / SHARD_ALIGN) * SHARD_ALIGN;
-    c->row0 = c->rank * c->rpr;
-    c->nrows = std::max(0, std::min(c->N - c->row0, c->rpr));
+    shard_rows(c->N, c->rank, c->world, &c->row0, &c->nrows, &c->rpr);
     c->ldF = (size_t)c->world * c->rpr;
 }
 
@@ -222,6 +226,18 @@ int dr_set_shard(dr_context* c, int rank, int world) {
     c->rank = rank; c->world = world;
     recompute_shard(c);
     return DR_OK;
+}
+
+int dr_shard_rows(int N, int rank, int world, int* row0, int* nrows, int* rpr) {
+    if (N < 1 || world < 1 || rank < 0 || rank >= world || !row0 || !nrows || !rpr)
+        return fail(DR_ERR_INVALID, "bad shard query N=%d rank=%d world=%d", N, rank, world);
+    shard_rows(N, rank, world, row0, nrows, rpr);
+    return DR_OK;
+}
+
+size_t dr_residual_offset(int i, int s, int S, int rpr) {
+    // chunk-major (one chunk per rank), bin-major inside a chunk: see sweep_kernels.hip
+    return ((size_t)(i / rpr) * S + s) * rpr + (size_t)(i % rpr);
 }
 
 int dr_get_shard(dr_context* c, int* row0, int* nrows, int* rpr) {

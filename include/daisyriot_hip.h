@@ -69,6 +69,11 @@ int dr_set_stream(dr_context* ctx, void* hip_stream);
  * dr_formfactors_assemble.  Default rank 0 / world 1 (all rows). */
 int dr_set_shard(dr_context* ctx, int rank, int world);
 int dr_get_shard(dr_context* ctx, int* row0, int* nrows, int* rows_per_rank);
+/* The same arithmetic without a context (pure host code, no GPU needed): which rows
+ * rank `rank` of `world` owns for N patches, and where element (patch i, bin s) of the
+ * residual lives in the gathered device buffer [world][S][rows_per_rank]. */
+int dr_shard_rows(int N, int rank, int world, int* row0, int* nrows, int* rows_per_rank);
+size_t dr_residual_offset(int i, int s, int S, int rows_per_rank);
 
 /* ---- scene --------------------------------------------------------------------- */
 /* Exactly the MeshS / SimpleMesh arrays (vs/MeshS.h:14-20, vs/Defines.h:14-23;

@@ -1,0 +1,69 @@
+"""Generates tests/golden/*.npz in THIS container from the reference's vendored glm 0.9.8.4
+and Eigen 3.2.10 (oracle/_ref/libref_check.so, built by oracle/Makefile from
+/root/reference/libraries where they lie).  Fixtures are data only: inputs + the values the
+reference's own math libraries produce at the hot path's call sites.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from daisyriot_amd import scenes  # noqa: E402
+from oracle import binding as ob  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    assert ob.ref_available(), "build oracle/_ref first (make -C oracle)"
+    rs = np.random.RandomState(7)
+    uv = scenes.visibility_samples(50)
+
+    # --- integrand + uv2xyz through glm ---------------------------------------------------
+    sc = scenes.cornell_box(96, S=3)
+    # perturb vertex normals so that avgNormal's average/normalise path is exercised
+    nrm = sc.normals + rs.normal(scale=0.05, size=sc.normals.shape).astype(np.float32)
+    tn = sc.tri_n.copy()
+    tn[:, 1] = (tn[:, 1] + 1) % nrm.shape[0]
+    m = ob.Mesh(sc.vertices, nrm, sc.tri_v, tn)
+    pairs = rs.randint(0, sc.N, size=(600, 2)).astype(np.int32)
+    pairs[:8] = [[k, k] for k in range(8)]                    # diagonal: NaN path -> stored 0
+    ff = np.array([ob.ref_p2p_integrand(m, i, j) for i, j in pairs], np.float32)
+    tri = rs.randint(0, sc.N, size=64).astype(np.int32)
+    pts = np.array([ob.ref_uv2xyz(m, t, uv[k % 50, 0], uv[k % 50, 1]) for k, t in enumerate(tri)], np.float32)
+    kat = np.float32(ob.ref_surface([0, 0, 0], [1, 0, 0], [0, 1, 0]))
+    np.savez_compressed(os.path.join(OUT, "integrand_glm.npz"), vertices=m.vertices, normals=m.normals,
+                        tri_v=m.tri_v, tri_n=m.tri_n, pairs=pairs, integrand_bits=ff.view(np.uint32),
+                        uv=uv, uv_tri=tri, uv_points_bits=pts.view(np.uint32), unit_triangle_area=kat)
+
+    # --- light passes through Eigen --------------------------------------------------------
+    for name, S, fluor, mode in (("spectral9", 9, True, 0), ("rgb3", 3, False, 1), ("bw1", 1, False, 0)):
+        sc = scenes.cornell_box(128, S=S, fluorescent=fluor)
+        mm = ob.Mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+        F, _, _ = ob.assemble_rows(mm, uv, bvh=True, want_vis=False)
+        M = sc.M.copy()
+        if name == "bw1":
+            M[:] = 1.0                                            # BWLightning: no reflectance (Lightning.h:419-424)
+        E = sc.emission(7.0)
+        R, B = E.copy(), E.copy()
+        snaps = {}
+        done = 0
+        for upto in (1, 2, 5, 20):
+            for _ in range(upto - done):
+                R, B = ob.ref_light_pass(F, M, sc.mat_of_patch, R, B, mode)
+            done = upto
+            snaps["R%d" % upto] = R.view(np.uint32).copy()
+            snaps["B%d" % upto] = B.view(np.uint32).copy()
+        sums = np.array([ob.ref_sum(R[:, s].copy()) for s in range(S)], np.float32)
+        np.savez_compressed(os.path.join(OUT, "lightpass_%s_eigen.npz" % name), F=F, M=M, E=E,
+                            mat=sc.mat_of_patch, mode=np.int32(mode), eigen_sums_R20=sums, **snaps)
+    print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))
+
+
+if __name__ == "__main__":
+    main()

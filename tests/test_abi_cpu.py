@@ -1,0 +1,67 @@
+"""The drop-in boundary without a GPU: the library loads, exports every symbol the header
+declares, the pure host arithmetic answers, and the product never reaches for the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from daisyriot_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "daisyriot_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared()
+    assert len(names) >= 25
+    lib = ctypes.CDLL(api.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libdaisyriot_hip.so does not export %s" % n
+    assert sorted(api.EXPORTS) == names, "daisyriot_amd/api.py binds a different set than the header declares"
+
+
+def test_header_cites_the_reference_for_each_entry_point():
+    src = open(os.path.join(ROOT, "include", "daisyriot_hip.h")).read()
+    assert src.count("vs/") >= 15
+
+
+def test_shard_arithmetic():
+    for N, world in ((65536, 8), (7712, 2), (300, 3), (1, 1), (262144, 8), (1000, 7)):
+        covered = 0
+        for r in range(world):
+            row0, nrows, rpr = api.shard_rows(N, r, world)
+            assert rpr % 256 == 0 and row0 == r * rpr and 0 <= nrows <= rpr
+            covered += nrows
+        assert covered == N and rpr * world >= N
+    assert api.shard_rows(65536, 3, 8) == (24576, 8192, 8192)
+    with pytest.raises(api.DaisyRiotError):
+        api.shard_rows(10, 2, 2)
+    # residual layout: chunk-major, bin-major inside a chunk
+    assert api.residual_offset(0, 0, 8, 256) == 0
+    assert api.residual_offset(5, 2, 8, 256) == 2 * 256 + 5
+    assert api.residual_offset(300, 2, 8, 256) == (1 * 8 + 2) * 256 + 44
+
+
+def test_errors_without_a_gpu_are_reported_not_swallowed():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(api.DaisyRiotError):
+        api.Context(0)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "daisyriot_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or f == "Makefile":
+                text = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+                assert "liboracle" not in text and "oracle.h" not in text, f
+    assert "oracle" not in open(os.path.join(pkg, "csrc", "Makefile")).read().replace("the oracle", "")

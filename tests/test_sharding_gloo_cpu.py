@@ -1,0 +1,76 @@
+"""The N>1 path on CPU: two gloo ranks run the row-sharded light-pass protocol of
+dr_solver_step (own rows -> own chunk of the gathered residual -> in-place all-gather ->
+next pass) using the library's own shard arithmetic (dr_shard_rows / dr_residual_offset,
+pure host code of libdaisyriot_hip.so).  The per-row arithmetic is the oracle's (there is
+no GPU here); the result must equal the unsharded oracle bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from daisyriot_amd import api, scenes
+from oracle import binding as ob
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, N, S, passes, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = scenes.cornell_box(N, S=S, fluorescent=True)
+    uv = scenes.visibility_samples(50)
+    row0, nrows, rpr = api.shard_rows(sc.N, rank, world)
+    m = ob.Mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+    # each rank assembles only its own rows (no communication in the assembly)
+    F, _, _ = ob.assemble_rows(m, uv, row0=row0, nrows=nrows, bvh=True, want_vis=False)
+    E = sc.emission(7.0)
+    # gathered residual in the device layout [world][S][rpr]
+    full = np.zeros(world * S * rpr, np.float32)
+    idx = np.array([[api.residual_offset(i, s, S, rpr) for s in range(S)] for i in range(sc.N)])
+    full[idx] = E
+    B = E[row0:row0 + nrows].copy()
+    for _ in range(passes):
+        Rin = full[idx]                                       # N x S view of the gathered buffer
+        Rout = ob.sweep_rows(F, sc.M, sc.mat_of_patch, Rin, B, row0=row0)
+        chunk = np.zeros(S * rpr, np.float32)                 # own chunk, bin-major, zero padded
+        for s in range(S):
+            chunk[s * rpr:s * rpr + nrows] = Rout[:, s]
+        gathered = torch.zeros(world * S * rpr)
+        dist.all_gather_into_tensor(gathered, torch.from_numpy(chunk))
+        full = gathered.numpy().copy()
+    np.save(os.path.join(out_dir, "B_%d.npy" % rank), B)
+    np.save(os.path.join(out_dir, "R_%d.npy" % rank), full[idx])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_passes_equal_unsharded(world, tmp_path):
+    N, S, passes = 300, 8, 4
+    mp.spawn(_rank_main, args=(world, _free_port(), N, S, passes, str(tmp_path)), nprocs=world, join=True)
+    sc = scenes.cornell_box(N, S=S, fluorescent=True)
+    m = ob.Mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+    F, _, _ = ob.assemble_rows(m, scenes.visibility_samples(50), bvh=True, want_vis=False)
+    E = sc.emission(7.0)
+    R, B = E.copy(), E.copy()
+    for _ in range(passes):
+        R = ob.sweep_rows(F, sc.M, sc.mat_of_patch, R, B)
+    Bs = []
+    for r in range(world):
+        row0, nrows, _ = api.shard_rows(N, r, world)
+        Br = np.load(tmp_path / ("B_%d.npy" % r))
+        assert Br.shape[0] == nrows
+        Bs.append(Br)
+        Rr = np.load(tmp_path / ("R_%d.npy" % r))
+        assert np.array_equal(Rr.view(np.uint32), R.view(np.uint32)), "rank %d holds a different residual" % r
+    assert np.array_equal(np.concatenate(Bs).view(np.uint32), B.view(np.uint32))
