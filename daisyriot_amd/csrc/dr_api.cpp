@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -49,7 +50,7 @@ struct dr_context {
     float *d_vtx = nullptr, *d_nrm = nullptr;
     int *d_tv = nullptr, *d_tn = nullptr;
     PatchRec* d_patch = nullptr;
-    TriRec* d_tri = nullptr;
+    TriRec *d_tri = nullptr, *d_tri_sorted = nullptr;
     BvhNode* d_bvh = nullptr;
     int n_nodes = 0;
     // shard
@@ -71,7 +72,7 @@ struct dr_context {
     Comm comm;
     // measurement
     double last_assemble_ms = 0, last_bvh_ms = 0;
-    unsigned long long pairs_traced = 0;
+    unsigned long long pairs_traced = 0, stat_visits = 0, stat_leaves = 0;
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
@@ -93,9 +94,9 @@ void free_solver(dr_context* c) {
 }
 void free_scene(dr_context* c) {
     hipFree(c->d_vtx); hipFree(c->d_nrm); hipFree(c->d_tv); hipFree(c->d_tn);
-    hipFree(c->d_patch); hipFree(c->d_tri); hipFree(c->d_bvh);
+    hipFree(c->d_patch); hipFree(c->d_tri); hipFree(c->d_tri_sorted); hipFree(c->d_bvh);
     c->d_vtx = c->d_nrm = nullptr; c->d_tv = c->d_tn = nullptr;
-    c->d_patch = nullptr; c->d_tri = nullptr; c->d_bvh = nullptr; c->N = 0;
+    c->d_patch = nullptr; c->d_tri = nullptr; c->d_tri_sorted = nullptr; c->d_bvh = nullptr; c->N = 0;
 }
 
 void shard_rows(int N, int rank, int world, int* row0, int* nrows, int* rpr) {
@@ -193,7 +194,7 @@ int dr_context_create(int device_id, dr_context** out) {
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(DR_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
-    e = hipMalloc(&c->d_counter, sizeof(unsigned long long));
+    e = hipMalloc(&c->d_counter, 4 * sizeof(unsigned long long));
     if (e != hipSuccess) { hipStreamDestroy(c->own_stream); delete c; return fail(DR_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
     *out = c;
     return DR_OK;
@@ -274,6 +275,7 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     HIPCHK(hipMalloc(&c->d_tn, sizeof(int) * 3 * (size_t)N));
     HIPCHK(hipMalloc(&c->d_patch, sizeof(PatchRec) * (size_t)N));
     HIPCHK(hipMalloc(&c->d_tri, sizeof(TriRec) * (size_t)N));
+    HIPCHK(hipMalloc(&c->d_tri_sorted, sizeof(TriRec) * ((size_t)N + LEAF_MAX)));
     c->n_nodes = 2 * N - 1;
     HIPCHK(hipMalloc(&c->d_bvh, sizeof(BvhNode) * (size_t)c->n_nodes));
     HIPCHK(hipMemcpyAsync(c->d_vtx, vertices, sizeof(float) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream));
@@ -285,7 +287,7 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, c->stream));
-    hipError_t be = build_lbvh(c->stream, N, c->d_tri, lo, hi, c->d_bvh);
+    hipError_t be = build_lbvh(c->stream, N, c->d_tri, lo, hi, c->d_bvh, c->d_tri_sorted, &c->n_nodes);
     if (be != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return fail(DR_ERR_DEVICE, "LBVH build failed: %s", hipGetErrorString(be)); }
     HIPCHK(hipEventRecord(e1, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -313,7 +315,7 @@ static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int r
         HIPCHK(hipMalloc(&c->d_uv, sizeof(float) * 2 * (size_t)K));
         HIPCHK(hipMemcpyAsync(c->d_uv, uv, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_counter, 0, 4 * sizeof(unsigned long long), c->stream));
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -323,16 +325,22 @@ static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int r
         p.N = c->N; p.K = trace ? K : 1; p.rule = rule; p.trace = trace;
         p.nT = (c->N + TILE - 1) / TILE; p.tile0 = c->row0 / TILE; p.nOwnedTiles = (c->nrows + TILE - 1) / TILE;
         p.row0 = c->row0; p.nrows = c->nrows; p.n_nodes = c->n_nodes; p.eps = eps; p.ldF = c->ldF;
-        p.F = c->d_F; p.vis = c->d_vis; p.patch = c->d_patch; p.tri = c->d_tri; p.bvh = c->d_bvh;
+        p.F = c->d_F; p.vis = c->d_vis; p.patch = c->d_patch; p.tri = c->d_tri; p.tri_sorted = c->d_tri_sorted; p.bvh = c->d_bvh;
         p.uv = c->d_uv; p.pairs_traced = c->d_counter;
+        p.stats = getenv("DR_TILE_STATS") ? 1 : 0;
         HIPCHK(launch_ff_tiles(c->stream, p));
     }
     HIPCHK(hipEventRecord(e1, c->stream));
-    HIPCHK(hipMemcpyAsync(&c->pairs_traced, c->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long cnt[4] = { 0, 0, 0, 0 };
+    HIPCHK(hipMemcpyAsync(cnt, c->d_counter, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     c->last_assemble_ms = ms;
+    c->pairs_traced = cnt[0]; c->stat_visits = cnt[1]; c->stat_leaves = cnt[2];
+    if (getenv("DR_TILE_STATS"))
+        fprintf(stderr, "[daisyriot] pairs %llu, node visits %llu (%.1f/pair), leaf tests %llu (%.1f/pair)\n", cnt[0], cnt[1],
+                cnt[0] ? (double)cnt[1] / cnt[0] : 0.0, cnt[2], cnt[0] ? (double)cnt[2] / cnt[0] : 0.0);
     hipEventDestroy(e0); hipEventDestroy(e1);
     c->have_F = true;
     return DR_OK;

@@ -19,16 +19,19 @@ struct PatchRec {
 // a, e1 = b-a, e2 = c-a : uv2xyz (vs/triangle_math.cpp:3-9) and the ray/triangle test
 struct TriRec {
     float a[3], e1[3], e2[3];
-    float pad[3];
-};                      // 12 floats = 48 B
+    int   id;           // original patch index (the leaf array is in Morton order)
+    float pad[2];
+};                      // 12 dwords = 48 B
 
 // Threaded BVH node in depth-first pre-order: the first child of an internal node is
 // node+1; `skip` is the pre-order index of the first node after this node's subtree.
 struct BvhNode {
     float lo[3], hi[3];
     int   skip;
-    int   tri;          // patch id for a leaf, -1 for an internal node
+    int   tri;          // leaf: first*8 + (count-1) into the Morton-ordered TriRec array; -1: internal
 };                      // 32 B: one s_load_dwordx8
+
+constexpr int LEAF_MAX = 4;     // subtrees of up to this many triangles are collapsed into one leaf
 
 constexpr int TILE = 64;        // patch-pair tile edge of the assembly kernel
 constexpr int SHARD_ALIGN = 256; // rows per rank are a multiple of this (sweep column tile)
@@ -40,10 +43,12 @@ struct TileParams {
     float* F;                 // this rank's rows: F[(row-row0)*ldF + col]
     unsigned char* vis;       // nullable, vis[(row-row0)*N + col]
     const PatchRec* patch;
-    const TriRec* tri;
+    const TriRec* tri;          // original order (ray generation)
+    const TriRec* tri_sorted;   // Morton order, LEAF_MAX padding records at the end (leaf tests)
     const BvhNode* bvh;
     const float* uv;          // K x 2
-    unsigned long long* pairs_traced;
+    unsigned long long* pairs_traced;   // [0] pairs traced, [1] BVH nodes visited, [2] leaves tested (wave level)
+    int stats;                          // count [1],[2] too (debug; costs two atomics per pair)
 };
 
 struct SweepParams {
@@ -68,7 +73,8 @@ struct SweepParams {
 hipError_t launch_patch_records(hipStream_t st, int N, const float* vtx, const float* nrm,
                                 const int* tv, const int* tn, PatchRec* patch, TriRec* tri);
 hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float scene_lo[3],
-                      const float scene_hi[3], BvhNode* nodes /* 2N-1 */);
+                      const float scene_hi[3], BvhNode* nodes /* room for 2N-1 */,
+                      TriRec* tri_sorted /* N + LEAF_MAX */, int* n_nodes_out);
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p);
 hipError_t launch_sweep(hipStream_t st, const SweepParams& p);
 hipError_t launch_colsums(hipStream_t st, const float* R, int world, int S, int rpr, double* sums);

@@ -82,7 +82,7 @@ __global__ void k_patch_records(int N, const float* __restrict__ vtx, const floa
     T.a[0] = a.x; T.a[1] = a.y; T.a[2] = a.z;
     T.e1[0] = e1.x; T.e1[1] = e1.y; T.e1[2] = e1.z;
     T.e2[0] = e2.x; T.e2[1] = e2.y; T.e2[2] = e2.z;
-    T.pad[0] = b.x; T.pad[1] = b.y; T.pad[2] = b.z;   // b kept for exact leaf bounds
+    T.id = t; T.pad[0] = 0.0f; T.pad[1] = 0.0f;
     tri[t] = T;
 }
 
@@ -109,8 +109,8 @@ __device__ __forceinline__ unsigned long long expand21(unsigned int v) {
 __device__ __forceinline__ void tri_bounds(const TriRec& T, float lo[3], float hi[3]) {
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        float pa = T.a[a], pb = T.pad[a], pc = T.a[a] + T.e2[a];
-        // c itself is not stored; a+e2 is within one rounding of it and the boxes are padded
+        float pa = T.a[a], pb = T.a[a] + T.e1[a], pc = T.a[a] + T.e2[a];
+        // (a, a+e1, a+e2) is the triangle the ray test sees; the boxes are padded on top
         lo[a] = fminf(pa, fminf(pb, pc));
         hi[a] = fmaxf(pa, fmaxf(pb, pc));
     }
@@ -172,60 +172,81 @@ __global__ void k_hierarchy(int N, const unsigned long long* __restrict__ keys, 
 
 __global__ void k_refit(int N, const TriRec* __restrict__ tri, const int* __restrict__ sorted_tri,
                         const int* __restrict__ left, const int* __restrict__ right,
+                        const int* __restrict__ first, const int* __restrict__ last,
                         const int* __restrict__ parent, int* __restrict__ flags,
-                        float* __restrict__ box /* (2N-1) x 6 */, float pad) {
+                        float* __restrict__ box /* (2N-1) x 6 */, int* __restrict__ esize /* 2N-1 */,
+                        TriRec* __restrict__ tri_sorted, float pad) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
+    const TriRec T = tri[sorted_tri[k]];
+    tri_sorted[k] = T;
     float lo[3], hi[3];
-    tri_bounds(tri[sorted_tri[k]], lo, hi);
+    tri_bounds(T, lo, hi);
     int id = N - 1 + k;
     float* b = box + 6 * (size_t)id;
     for (int a = 0; a < 3; a++) { lo[a] -= pad; hi[a] += pad; b[a] = lo[a]; b[3 + a] = hi[a]; }
+    esize[id] = 1;
+    int es = 1;                                 // nodes this subtree contributes to the output
     int p = (N > 1) ? parent[id] : -1;
     while (p >= 0) {
-        __threadfence();                       // publish this subtree's box (agent scope)
+        __threadfence();                       // publish this subtree's box and size (agent scope)
         int old = atomicAdd(&flags[p], 1);
         if (old == 0) return;                  // the sibling's thread continues upwards
-        __threadfence();                       // acquire the sibling's box
+        __threadfence();                       // acquire the sibling's box and size
         int sib = (left[p] == id) ? right[p] : left[p];
         const volatile float* sb = box + 6 * (size_t)sib;
         for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], sb[a]); hi[a] = fmaxf(hi[a], sb[3 + a]); }
         float* pb = box + 6 * (size_t)p;
         for (int a = 0; a < 3; a++) { pb[a] = lo[a]; pb[3 + a] = hi[a]; }
+        const int sib_es = ((const volatile int*)esize)[sib];
+        es = (last[p] - first[p] + 1 <= LEAF_MAX) ? 1 : 1 + es + sib_es;
+        esize[p] = es;
         id = p;
         p = parent[p];
     }
 }
 
-__global__ void k_emit(int N, const int* __restrict__ sorted_tri, const int* __restrict__ left,
-                       const int* __restrict__ first, const int* __restrict__ last,
-                       const int* __restrict__ parent, const float* __restrict__ box,
+// A node is written iff no proper ancestor is collapsed; it is a leaf iff it covers at most
+// LEAF_MAX triangles.  Its pre-order index counts, on the way to the root, one per ancestor
+// plus the written size of every left sibling subtree.
+__global__ void k_emit(int N, const int* __restrict__ left, const int* __restrict__ first,
+                       const int* __restrict__ last, const int* __restrict__ parent,
+                       const float* __restrict__ box, const int* __restrict__ esize,
                        BvhNode* __restrict__ nodes) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= 2 * N - 1) return;
-    int size = (id < N - 1) ? 2 * (last[id] - first[id]) + 1 : 1;
+    const bool internal = id < N - 1;
+    const int f = internal ? first[id] : id - (N - 1);
+    const int cnt = internal ? last[id] - first[id] + 1 : 1;
     int idx = 0;
     int cur = id;
     while (cur != 0 && N > 1) {
         int p = parent[cur];
-        if (left[p] == cur) idx += 1;
-        else {
-            int lc = left[p];
-            int lsize = (lc < N - 1) ? 2 * (last[lc] - first[lc]) + 1 : 1;
-            idx += 1 + lsize;
-        }
+        if (last[p] - first[p] + 1 <= LEAF_MAX) return;      // inside a collapsed subtree
+        idx += 1;
+        if (left[p] != cur) idx += esize[left[p]];
         cur = p;
     }
     BvhNode nd;
     const float* b = box + 6 * (size_t)id;
     for (int a = 0; a < 3; a++) { nd.lo[a] = b[a]; nd.hi[a] = b[3 + a]; }
-    nd.skip = idx + size;
-    nd.tri = (id < N - 1) ? -1 : sorted_tri[id - (N - 1)];
+    nd.skip = idx + esize[id];
+    nd.tri = (cnt <= LEAF_MAX) ? f * 8 + (cnt - 1) : -1;
     nodes[idx] = nd;
 }
 
+__global__ void k_pad_tris(int N, TriRec* __restrict__ tri_sorted) {
+    int k = threadIdx.x;
+    if (k < LEAF_MAX) {                 // records a leaf's fixed-width fetch may touch past the end
+        TriRec T;
+        for (int a = 0; a < 3; a++) { T.a[a] = 0.0f; T.e1[a] = 0.0f; T.e2[a] = 0.0f; }
+        T.id = -1; T.pad[0] = T.pad[1] = 0.0f;
+        tri_sorted[N + k] = T;
+    }
+}
+
 hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[3], const float shi[3],
-                      BvhNode* nodes) {
+                      BvhNode* nodes, TriRec* tri_sorted, int* n_nodes_out) {
     hipError_t e;
     unsigned long long *keys = nullptr, *keys2 = nullptr;
     int *vals = nullptr, *vals2 = nullptr, *ibuf = nullptr;
@@ -244,12 +265,13 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
     DR_TRY(hipMalloc(&keys2, sizeof(unsigned long long) * N));
     DR_TRY(hipMalloc(&vals, sizeof(int) * N));
     DR_TRY(hipMalloc(&vals2, sizeof(int) * N));
-    // left,right,first,last,flags: N-1 each; parent: 2N-1
-    DR_TRY(hipMalloc(&ibuf, sizeof(int) * (5 * (size_t)N + nn)));
+    // left,right,first,last,flags: N-1 each; parent, esize: 2N-1 each
+    DR_TRY(hipMalloc(&ibuf, sizeof(int) * (5 * (size_t)N + 2 * nn)));
     DR_TRY(hipMalloc(&box, sizeof(float) * 6 * nn));
     {
         int* left = ibuf; int* right = ibuf + N; int* first = ibuf + 2 * (size_t)N;
         int* last = ibuf + 3 * (size_t)N; int* flags = ibuf + 4 * (size_t)N; int* parent = ibuf + 5 * (size_t)N;
+        int* esize = parent + nn;
         const int nb = (N + 255) / 256;
         hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, st, N, tri, lo3, inv3, keys, vals);
         DR_TRY(hipGetLastError());
@@ -261,10 +283,15 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
             hipLaunchKernelGGL(k_hierarchy, dim3(nb), dim3(256), 0, st, N, keys2, left, right, first, last, parent);
             DR_TRY(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_refit, dim3(nb), dim3(256), 0, st, N, tri, vals2, left, right, parent, flags, box, pad);
+        hipLaunchKernelGGL(k_refit, dim3(nb), dim3(256), 0, st, N, tri, vals2, left, right, first, last, parent, flags,
+                           box, esize, tri_sorted, pad);
         DR_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_emit, dim3((int)((nn + 255) / 256)), dim3(256), 0, st, N, vals2, left, first, last, parent, box, nodes);
+        hipLaunchKernelGGL(k_pad_tris, dim3(1), dim3(64), 0, st, N, tri_sorted);
         DR_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_emit, dim3((int)((nn + 255) / 256)), dim3(256), 0, st, N, left, first, last, parent, box, esize, nodes);
+        DR_TRY(hipGetLastError());
+        // nodes written = size of the root's subtree (a lone triangle is its own root leaf)
+        DR_TRY(hipMemcpyAsync(n_nodes_out, esize, sizeof(int), hipMemcpyDeviceToHost, st));
         DR_TRY(hipStreamSynchronize(st));
     }
 #undef DR_TRY
@@ -292,13 +319,15 @@ __device__ __forceinline__ bool tri_hit(f3 o, f3 d, f3 a, f3 e1, f3 e2, float& t
     return (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t > 0.0f);
 }
 
-// conservative slab test of the segment [0,tmax] against a (padded) box held in SGPRs
-__device__ __forceinline__ bool box_hit(const BvhNode& nd, f3 o, f3 inv, float tmax) {
-    float t0 = (nd.lo[0] - o.x) * inv.x, t1 = (nd.hi[0] - o.x) * inv.x;
+// conservative slab test of the segment [0,tmax] against a (padded) box held in SGPRs.
+// t = plane*inv - org*inv as one fused multiply-add per plane (noi = -org*inv per lane): the box
+// test only has to be conservative (boxes are padded by 1e-4 of the scene), not bit-exact.
+__device__ __forceinline__ bool box_hit(const BvhNode& nd, f3 noi, f3 inv, float tmax) {
+    float t0 = __builtin_fmaf(nd.lo[0], inv.x, noi.x), t1 = __builtin_fmaf(nd.hi[0], inv.x, noi.x);
     float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
-    t0 = (nd.lo[1] - o.y) * inv.y; t1 = (nd.hi[1] - o.y) * inv.y;
+    t0 = __builtin_fmaf(nd.lo[1], inv.y, noi.y); t1 = __builtin_fmaf(nd.hi[1], inv.y, noi.y);
     tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-    t0 = (nd.lo[2] - o.z) * inv.z; t1 = (nd.hi[2] - o.z) * inv.z;
+    t0 = __builtin_fmaf(nd.lo[2], inv.z, noi.z); t1 = __builtin_fmaf(nd.hi[2], inv.z, noi.z);
     tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
     return (tn <= tf * 1.00001f) && (tf >= 0.0f) && (tn <= tmax);
 }
@@ -312,12 +341,50 @@ __device__ __forceinline__ float safe_inv(float d) {
 // fused tile kernel
 // ---------------------------------------------------------------------------------------
 constexpr int REC_STRIDE = 21;      // 20 floats + 1: conflict-free LDS rows
-constexpr int TA_STRIDE = TILE + 1;
 constexpr int VIS_STRIDE = TILE + 4;
 
 __device__ __forceinline__ float stored(float f) { return f > 0.0f ? f : 0.0f; }
 
-template <int NT>
+// Stored integrand of both directions of the pair (i in the I block, j in the J block) from the
+// per-patch records (vs/triangle_math.cpp:49-58 summed as vs/OptixPrimeFunctionality.cpp:153-161).
+// The 16 point terms of (i,s)->(j,u) and (j,u)->(i,s) are bitwise equal, so they are formed once
+// and added in the two orders the reference uses: fa = F(i->j), fb = F(j->i).
+__device__ __forceinline__ void integrand_pair(const float* ri, const float* rj, float& fa, float& fb) {
+    const f3 ni = f3{ ri[12], ri[13], ri[14] }, nj = f3{ rj[12], rj[13], rj[14] };
+    float ff[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const f3 ci = f3{ ri[3 * s], ri[3 * s + 1], ri[3 * s + 2] };
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const f3 cj = f3{ rj[3 * u], rj[3 * u + 1], rj[3 * u + 2] };
+            f3 d = cj - ci;
+            float len = sqrtf(dot3(d, d));
+            f3 dn = d * (1.0f / len);
+            float c1 = dot3(ni, dn);
+            float c2 = -dot3(nj, dn);
+            float v = 0.0f;
+            if (c1 > 0.0f && c2 > 0.0f) v = ((c1 * c2) / ((len * len) * DR_PIF)) * (ri[15 + s] * rj[15 + u]);
+            ff[s][u] = v;
+        }
+    }
+    float accA = 0.0f, accB = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) accA = accA + ff[s][u];     // i's sub-triangles outer
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) accB = accB + ff[s][u];     // j's sub-triangles outer
+    fa = stored(accA / ri[19]);
+    fb = stored(accB / rj[19]);
+}
+
+// STATS builds count BVH visits with global atomics inside the pair loop; that store makes
+// the compiler give up scalar (SMEM) loads for nodes and triangles, so it is a separate,
+// debug-only instantiation.
+template <int NT, bool STATS>
 __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
     const int t = blockIdx.x;
     const int o = P.tile0 + blockIdx.y;
@@ -330,9 +397,7 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
     const bool ownJ = (bj >= P.tile0) && (bj < P.tile0 + P.nOwnedTiles);
 
     __shared__ float sRec[2][TILE][REC_STRIDE];
-    __shared__ float sA[TILE][TA_STRIDE];     // stored integrand I->J
-    __shared__ float sB[TILE][TA_STRIDE];     // stored integrand J->I
-    __shared__ unsigned char sVis[TILE][VIS_STRIDE];
+    __shared__ unsigned char sVis[TILE][VIS_STRIDE];   // ray count per pair, 255 = not traced
     __shared__ unsigned short sQueue[TILE * TILE];
     __shared__ int sCount;
 
@@ -348,52 +413,20 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
     }
     __syncthreads();
 
-    // ---- integrand for both directions of every pair of the tile ------------------------
-    for (int p = tid; p < TILE * TILE; p += NT) {
+    // ---- which pairs are traced: stored integrand lo->hi > 0 (vs/OptixPrimeFunctionality.cpp:190)
+    for (int p0 = 0; p0 < TILE * TILE; p0 += NT) {
+        const int p = p0 + tid;
         const int i = p >> 6, j = p & 63;
         const int gi = I0 + i, gj = J0 + j;
-        const bool valid = (gi < P.N) && (gj < P.N) && (gi < gj);
-        float fa = 0.0f, fb = 0.0f;
-        if (valid) {
-            const float* ri = sRec[0][i];
-            const float* rj = sRec[1][j];
-            const f3 ni = f3{ ri[12], ri[13], ri[14] }, nj = f3{ rj[12], rj[13], rj[14] };
-            float ff[4][4];
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const f3 ci = f3{ ri[3 * s], ri[3 * s + 1], ri[3 * s + 2] };
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const f3 cj = f3{ rj[3 * u], rj[3 * u + 1], rj[3 * u + 2] };
-                    // vs/triangle_math.cpp:49-58 for origin (i,s), destination (j,u); the
-                    // reverse direction's term is bitwise the same value
-                    f3 d = cj - ci;
-                    float len = sqrtf(dot3(d, d));
-                    f3 dn = d * (1.0f / len);
-                    float c1 = dot3(ni, dn);
-                    float c2 = -dot3(nj, dn);
-                    float v = 0.0f;
-                    if (c1 > 0.0f && c2 > 0.0f) v = ((c1 * c2) / ((len * len) * DR_PIF)) * (ri[15 + s] * rj[15 + u]);
-                    ff[s][u] = v;
-                }
+        bool act = false;
+        if (p < TILE * TILE) {
+            if ((gi < P.N) && (gj < P.N) && (gi < gj)) {
+                float fa, fb;
+                integrand_pair(sRec[0][i], sRec[1][j], fa, fb);
+                act = fa > 0.0f;
             }
-            float accA = 0.0f, accB = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 4; s++)
-#pragma unroll
-                for (int u = 0; u < 4; u++) accA = accA + ff[s][u];     // i's sub-triangles outer
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-#pragma unroll
-                for (int s = 0; s < 4; s++) accB = accB + ff[s][u];     // j's sub-triangles outer
-            fa = stored(accA / ri[19]);
-            fb = stored(accB / rj[19]);
+            sVis[i][j] = 255;
         }
-        sA[i][j] = fa;
-        sB[i][j] = fb;
-        sVis[i][j] = 255;
-        // pairs to trace: stored integrand lo->hi > 0 (vs/OptixPrimeFunctionality.cpp:190)
-        const bool act = valid && (fa > 0.0f);
         const unsigned long long m = __ballot(act);
         int base = 0;
         if (lane == 0 && m) base = atomicAdd(&sCount, __popcll(m));
@@ -417,6 +450,7 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
             const f3 la = ld3(Tl.a), le1 = ld3(Tl.e1), le2 = ld3(Tl.e2);
             const f3 ha = ld3(Th.a), he1 = ld3(Th.e1), he2 = ld3(Th.e2);
             int count = 0;
+            int n_visit = 0, n_leaf = 0;
             for (int k0 = 0; k0 < P.K; k0 += 64) {
                 const int k = k0 + lane;
                 bool alive = k < P.K;
@@ -434,21 +468,34 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
                     alive = tri_hit(org, dn, ha, he1, he2, tmax);   // the destination must be hit at all
                 }
                 const f3 inv = f3{ safe_inv(dn.x), safe_inv(dn.y), safe_inv(dn.z) };
+                const f3 noi = f3{ -(org.x * inv.x), -(org.y * inv.y), -(org.z * inv.z) };
                 int node = 0;
                 // every step moves forward in pre-order, so n_nodes steps bound the walk even
                 // if the node array were corrupt (no wave may spin forever on the device)
                 for (int guard = 0; guard < P.n_nodes && node < P.n_nodes; guard++) {
                     if (__ballot(alive) == 0ull) break;
                     const BvhNode nd = P.bvh[node];
-                    const bool hb = alive && box_hit(nd, org, inv, tmax);
+                    n_visit++;
+                    const bool hb = alive && box_hit(nd, noi, inv, tmax);
                     if (__ballot(hb) == 0ull) { node = __builtin_amdgcn_readfirstlane(nd.skip); continue; }
-                    const int tk = __builtin_amdgcn_readfirstlane(nd.tri);
-                    if (tk >= 0 && tk != hi) {
-                        const TriRec Tk = P.tri[tk];
-                        float tt;
-                        if (hb && tri_hit(org, dn, ld3(Tk.a), ld3(Tk.e1), ld3(Tk.e2), tt)) {
-                            // closest hit is not `hi`: something nearer, or an equal-t hit of lower id
-                            if (tt < tmax || (tt == tmax && tk < hi)) alive = false;
+                    const int leaf = __builtin_amdgcn_readfirstlane(nd.tri);
+                    if (leaf >= 0) {
+                        n_leaf++;
+                        const int first = leaf >> 3, cnt = (leaf & 7) + 1;
+                        // fixed-width fetch (the array is padded) so the scalar loads issue together
+                        TriRec Tk[LEAF_MAX];
+#pragma unroll
+                        for (int c = 0; c < LEAF_MAX; c++) Tk[c] = P.tri_sorted[first + c];
+#pragma unroll
+                        for (int c = 0; c < LEAF_MAX; c++) {
+                            const int tk = Tk[c].id;
+                            if (c < cnt && tk != hi) {
+                                float tt;
+                                if (hb && tri_hit(org, dn, ld3(Tk[c].a), ld3(Tk[c].e1), ld3(Tk[c].e2), tt)) {
+                                    // closest hit is not `hi`: something nearer, or an equal-t hit of lower id
+                                    if (tt < tmax || (tt == tmax && tk < hi)) alive = false;
+                                }
+                            }
                         }
                     }
                     node = node + 1;
@@ -456,13 +503,16 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
                 count += __popcll(__ballot(alive));
             }
             if (lane == 0) sVis[i][j] = (unsigned char)count;
+            if (STATS && lane == 0) {
+                atomicAdd(P.pairs_traced + 1, (unsigned long long)n_visit);
+                atomicAdd(P.pairs_traced + 2, (unsigned long long)n_leaf);
+            }
         }
     }
     __syncthreads();
-
     if (tid == 0 && n_act > 0 && P.trace && P.pairs_traced) atomicAdd(P.pairs_traced, (unsigned long long)n_act);
 
-    // ---- write both F tiles once, coalesced ---------------------------------------------
+    // ---- write both F tiles once, coalesced (the integrand is recomputed rather than kept in LDS)
     const float Kf = (float)P.K;
     for (int pass = 0; pass < 2; pass++) {
         // pass 0: rows of the I block (F[I0+r][J0+c]); pass 1: rows of the J block (F[J0+r][I0+c])
@@ -480,17 +530,20 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
             unsigned char vc = 255;
             if (gr != gc) {
                 vc = sVis[i][j];
-                const float fu_f = sA[i][j], fu_r = sB[i][j];
-                if (fu_f > 0.0f) {
-                    const float V = P.trace ? (float)vc / Kf : 1.0f;
-                    if (!P.trace) vc = 255;
-                    if (P.rule == 0) {
-                        if (V > 0.0f) val = V * (fwd ? fu_f : fu_r);
-                    } else {
-                        const float f = fu_f * V;
-                        if (f > 0.0f) val = fwd ? f : (sRec[0][i][19] * f) / sRec[1][j][19];
+                if (vc != 255 || !P.trace) {
+                    float fu_f, fu_r;
+                    integrand_pair(sRec[0][i], sRec[1][j], fu_f, fu_r);
+                    if (fu_f > 0.0f) {
+                        const float V = P.trace ? (float)vc / Kf : 1.0f;
+                        if (P.rule == 0) {
+                            if (V > 0.0f) val = V * (fwd ? fu_f : fu_r);
+                        } else {
+                            const float f = fu_f * V;
+                            if (f > 0.0f) val = fwd ? f : (sRec[0][i][19] * f) / sRec[1][j][19];
+                        }
                     }
                 }
+                if (!P.trace) vc = 255;
             }
             P.F[(size_t)(gr - P.row0) * P.ldF + gc] = val;
             if (P.vis) P.vis[(size_t)(gr - P.row0) * P.N + gc] = vc;
@@ -498,10 +551,23 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
     }
 }
 
+static int tile_threads() {
+    static int nt = -1;
+    if (nt < 0) { const char* e = getenv("DR_TILE_THREADS"); nt = e ? atoi(e) : 256; }
+    return nt;
+}
+
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p) {
-    constexpr int NT = 512;
     dim3 grid(p.nT, p.nOwnedTiles);
-    hipLaunchKernelGGL(k_ff_tiles<NT>, grid, dim3(NT), 0, st, p);
+    if (p.stats) {
+        hipLaunchKernelGGL((k_ff_tiles<256, true>), grid, dim3(256), 0, st, p);
+        return hipGetLastError();
+    }
+    switch (tile_threads()) {
+        case 512: hipLaunchKernelGGL((k_ff_tiles<512, false>), grid, dim3(512), 0, st, p); break;
+        case 1024: hipLaunchKernelGGL((k_ff_tiles<1024, false>), grid, dim3(1024), 0, st, p); break;
+        default: hipLaunchKernelGGL((k_ff_tiles<256, false>), grid, dim3(256), 0, st, p); break;
+    }
     return hipGetLastError();
 }
 

@@ -240,3 +240,26 @@ def test_full_size_properties(uv50):
         sums = [c.step(1, want_sum=True) for _ in range(6)]
         assert all(b < a for a, b in zip(sums, sums[1:]))
     assert info.pairs_traced > 0
+
+
+def test_bvh_invariants():
+    """threaded LBVH: pre-order skips, every patch in exactly one leaf, leaves inside their boxes"""
+    sc = scenes.cornell_box(3000, S=1)
+    with _ctx(sc) as c:
+        b = c.read_bvh()
+    n = len(b)
+    assert np.all(b["skip"] > np.arange(n)) and np.all(b["skip"] <= n) and b["skip"][0] == n
+    leaf = b["tri"] >= 0
+    first, cnt = b["tri"][leaf] >> 3, (b["tri"][leaf] & 7) + 1
+    assert cnt.sum() == sc.N and cnt.max() <= 4
+    order = np.argsort(first)
+    assert np.array_equal(first[order], np.r_[0, np.cumsum(cnt[order])[:-1]])     # leaves tile the sorted array
+    assert np.all(b["skip"][leaf] == np.nonzero(leaf)[0] + 1)                     # a leaf's subtree is itself
+    internal = np.nonzero(~leaf)[0]
+    for i in internal[:: max(1, len(internal) // 300)]:                           # children inside the parent
+        l, r = i + 1, b["skip"][i + 1]
+        for ch in (l, r):
+            assert np.all(b["lo"][ch] >= b["lo"][i]) and np.all(b["hi"][ch] <= b["hi"][i])
+        assert b["skip"][r] == b["skip"][i]
+    lo, hi = sc.vertices.min(0), sc.vertices.max(0)
+    assert np.all(b["lo"][0] <= lo) and np.all(b["hi"][0] >= hi)
