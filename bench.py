@@ -35,6 +35,20 @@ def sweep_bytes(nrows, N, S, n_mat):
     return 4 * nrows * N + 4 * N * S + 4 * nrows * S * 3 + 4 * n_mat * S * S
 
 
+def pmc_traffic(N, S, world):
+    """HBM bytes per sweep launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    collected in separate runs, gfx950 corrections applied: profiles/r01/pmc_summary.md), when they
+    were taken on this exact workload; None otherwise (PMC counters cannot be read live here)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_sweep_64k.json")))
+        w = d["workload"]
+        if (w["patches"], w["bins"], w["world"]) == (N, S, world):
+            return d["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baselines(ctx, sc, uv, n_rows_sweep, n_rows_ff):
     """The oracle (a CPU port of the reference's algorithm) timed on this box's host cores
     on a bounded row sample of the same workload; single thread, like the reference."""
@@ -184,7 +198,7 @@ def main():
                        "patches": N, "bins": S, "rays_per_pair": args.rays,
                        "F_bytes_per_gpu": int(info.bytes_F), "rows_per_gpu": int(info.nrows)},
             "roofline": {"bound": "hbm", "kernel": "k_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(N, S, world),
                          "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": kern_ms,
                          "launches_timed": int(info.sweep_launches)},
             "formfactors": {"value": N * (N - 1) / t_asm, "unit": "pairs/s", "seconds": t_asm,
