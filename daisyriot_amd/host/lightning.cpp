@@ -1,0 +1,216 @@
+#include "lightning.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <random>
+
+namespace daisy {
+
+std::vector<UV> make_visibility_samples(int K, unsigned seed) {
+    std::mt19937 gen(seed);
+    std::vector<UV> r((size_t)K);
+    for (int i = 0; i < K; i++) {
+        // the reference draws rand()%RAND_MAX / RAND_MAX with MSVC's 15-bit rand; same lattice here
+        float u = (float)(gen() % 32767u) / 32767.0f;
+        float v = (float)(gen() % 32767u) / 32767.0f;
+        r[(size_t)i] = UV{ u, v * (1 - u) };
+    }
+    return r;
+}
+
+namespace {
+
+void chk(int rc, const char* what) {
+    if (rc != DR_OK) throw HipError(std::string(what) + ": " + dr_last_error());
+}
+
+// CIE 1931 colour-matching fit of Wyman, Sloan, Shirley (JCGT 2013), as color.h:14-45 uses it
+vec3 cie_xyz(double w) {
+    auto g = [](double x, double mu, double s1, double s2) { double t = (x - mu) * (x < mu ? s1 : s2); return std::exp(-0.5 * t * t); };
+    double x = 0.362 * g(w, 442.0, 0.0624, 0.0374) + 1.056 * g(w, 599.8, 0.0264, 0.0323) - 0.065 * g(w, 501.1, 0.0490, 0.0382);
+    double y = 0.821 * g(w, 568.8, 0.0213, 0.0247) + 0.286 * g(w, 530.9, 0.0613, 0.0322);
+    double z = 1.217 * g(w, 437.0, 0.0845, 0.0278) + 0.681 * g(w, 459.0, 0.0385, 0.0725);
+    return vec3{ (float)x, (float)y, (float)z };
+}
+vec3 xyz_to_rgb(const vec3& c) {        // color.h:48-52
+    return vec3{ 3.240479f * c.x - 1.537150f * c.y - 0.498535f * c.z,
+                 -0.969256f * c.x + 1.875991f * c.y + 0.041556f * c.z,
+                 0.055648f * c.x - 0.204043f * c.y + 1.057311f * c.z };
+}
+
+// Reader/writer of the reference's F cache (Lightning.h:21-74): ints rows, cols, nnz, outerSize, innerSize,
+// then float values[nnz], int outerIndex[outerSize] (not outerSize+1), int innerIndex[nnz] of the
+// column-major compressed matrix RadMat(i,j) = F(i->j).
+bool read_fcache(const char* path, int N, std::vector<float>& dense) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) return false;
+    int hdr[5];
+    f.read((char*)hdr, sizeof hdr);
+    if (!f || hdr[0] != N || hdr[1] != N || hdr[2] < 0 || hdr[3] != N) return false;
+    const int nnz = hdr[2];
+    std::vector<float> val((size_t)nnz);
+    std::vector<int> outer((size_t)N + 1), inner((size_t)nnz);
+    f.read((char*)val.data(), sizeof(float) * (size_t)nnz);
+    f.read((char*)outer.data(), sizeof(int) * (size_t)N);
+    f.read((char*)inner.data(), sizeof(int) * (size_t)nnz);
+    if (!f) return false;
+    outer[(size_t)N] = nnz;
+    dense.assign((size_t)N * N, 0.0f);
+    for (int col = 0; col < N; col++)
+        for (int k = outer[(size_t)col]; k < outer[(size_t)col + 1]; k++) {
+            if (k < 0 || k >= nnz || inner[(size_t)k] < 0 || inner[(size_t)k] >= N) return false;
+            dense[(size_t)inner[(size_t)k] * N + col] = val[(size_t)k];
+        }
+    return true;
+}
+void write_fcache(const char* path, int N, const std::vector<float>& dense) {
+    std::vector<float> val;
+    std::vector<int> outer((size_t)N), inner;
+    for (int col = 0; col < N; col++) {
+        outer[(size_t)col] = (int)val.size();
+        for (int row = 0; row < N; row++) {
+            float v = dense[(size_t)row * N + col];
+            if (v != 0.0f) { val.push_back(v); inner.push_back(row); }
+        }
+    }
+    std::ofstream f(path, std::ios::binary);
+    if (!f.is_open()) return;
+    int hdr[5] = { N, N, (int)val.size(), N, N };
+    f.write((const char*)hdr, sizeof hdr);
+    f.write((const char*)val.data(), sizeof(float) * val.size());
+    f.write((const char*)outer.data(), sizeof(int) * outer.size());
+    f.write((const char*)inner.data(), sizeof(int) * inner.size());
+}
+
+class LightningHIP : public Lightning {
+public:
+    LightningHIP(int method, MeshS& mesh, float emission_value, const std::vector<float>& wavelengths, bool cuda_rule,
+                 const char* matfile, int device, int max_passes)
+        : method_(method), max_passes_(max_passes), mesh_(mesh) {
+        N_ = mesh.numtriangles;
+        if (N_ <= 0) throw HipError("mesh has no triangles");
+        const int n_mat = (int)mesh.materials.size();
+        std::vector<float> E, M;
+        if (method == 2) {                       // SpectralLightning (Lightning.h:114-139, 263-292)
+            S_ = (int)wavelengths.size();
+            threshold_ = 200.0f; per_bin_ = false;            // Lightning.h:146
+            E.assign((size_t)N_ * S_, 0.0f);
+            for (int j = 0; j < N_; j++)
+                for (int s = 0; s < S_; s++) {
+                    float e = mesh.materials[(size_t)mesh.materialIndexPerTriangle[(size_t)j]].spectral_emission[(size_t)s];
+                    if (e > 0.0f) E[(size_t)j * S_ + s] = e * emission_value;
+                }
+            for (const Material& m : mesh.materials) M.insert(M.end(), m.M.begin(), m.M.end());
+            for (float w : wavelengths) xyz_.push_back(cie_xyz(w));
+        } else if (method == 1) {                // RGBLightning (Lightning.h:317-382)
+            S_ = 3;
+            threshold_ = 0.0001f; per_bin_ = true;            // Lightning.h:337
+            E.assign((size_t)N_ * 3, 0.0f);
+            for (int j = 0; j < N_; j++)
+                for (int s = 0; s < 3; s++) {
+                    float e = mesh.materials[(size_t)mesh.materialIndexPerTriangle[(size_t)j]].emission[s];
+                    if (e > 0.0f) E[(size_t)j * 3 + s] = e * emission_value;
+                }
+            for (const Material& m : mesh.materials)
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < 3; b++) M.push_back(a == b && m.rgbcolor[a] > 0.0f ? m.rgbcolor[a] : 0.0f);
+        } else {                                  // BWLightning (Lightning.h:386-443): no reflectance
+            S_ = 1;
+            threshold_ = 0.0001f; per_bin_ = false;           // Lightning.h:411
+            E.assign((size_t)N_, 0.0f);
+            for (int j = 0; j < N_; j++) {
+                float e = mesh.materials[(size_t)mesh.materialIndexPerTriangle[(size_t)j]].emission[0];
+                if (e > 0.0f) E[(size_t)j] = e * emission_value;
+            }
+            M.assign((size_t)n_mat, 1.0f);
+        }
+        chk(dr_context_create(device, &ctx_), "dr_context_create");
+        std::vector<int32_t> tv((size_t)3 * N_), tn((size_t)3 * N_);
+        for (int t = 0; t < N_; t++)
+            for (int k = 0; k < 3; k++) {
+                tv[(size_t)3 * t + k] = mesh.triangleIndices[(size_t)t].vertex[k];
+                tn[(size_t)3 * t + k] = mesh.triangleIndices[(size_t)t].normal[k];
+            }
+        chk(dr_scene_set_mesh(ctx_, &mesh.vertices[0].x, (int)mesh.vertices.size(), &mesh.normals[0].x,
+                              (int)mesh.normals.size(), tv.data(), tn.data(), N_), "dr_scene_set_mesh");
+        // initMat / initMatFromFile (Lightning.h:75-96)
+        std::vector<float> dense;
+        if (matfile && read_fcache(matfile, N_, dense)) {
+            chk(dr_formfactors_load_rows(ctx_, 0, N_, dense.data()), "dr_formfactors_load_rows");
+            std::printf("Deserialized matrix\n");
+        } else {
+            std::vector<UV> rands = make_visibility_samples();
+            chk(dr_formfactors_assemble(ctx_, &rands[0].u, (int)rands.size(), DR_ORIGIN_EPS,
+                                        cuda_rule ? DR_RULE_INTEGRAND : DR_RULE_RECIPROCITY, 0), "dr_formfactors_assemble");
+            if (matfile && (size_t)N_ * N_ <= ((size_t)1 << 28)) {
+                dense.resize((size_t)N_ * N_);
+                chk(dr_formfactors_read_rows(ctx_, 0, N_, dense.data()), "dr_formfactors_read_rows");
+                write_fcache(matfile, N_, dense);
+                std::printf("Loaded & Serialized matrix\n");
+            }
+        }
+        chk(dr_solver_init(ctx_, S_, E.data(), M.data(), n_mat, mesh.materialIndexPerTriangle.data()), "dr_solver_init");
+        B_.assign((size_t)N_ * S_, 0.0f);
+        refresh();
+        numpasses_ = 0;
+        std::printf("Lightning has been initialized\n");
+        converge_lightning();
+    }
+    ~LightningHIP() override { dr_context_destroy(ctx_); }
+
+    vec3 get_color_of_patch(int i) override {
+        const float* b = &B_[(size_t)i * S_];
+        if (method_ == 1) return vec3{ b[0], b[1], b[2] };                   // Lightning.h:332-334
+        if (method_ == 0) return vec3{ b[0], b[0], b[0] };                   // Lightning.h:406-408
+        vec3 xyz{ 0, 0, 0 };                                                 // Lightning.h:168-183
+        for (int s = 0; s < S_; s++) { xyz.x += xyz_[(size_t)s].x * b[s]; xyz.y += xyz_[(size_t)s].y * b[s]; xyz.z += xyz_[(size_t)s].z * b[s]; }
+        vec3 rgb = xyz_to_rgb(xyz);
+        float mx = std::fmax(rgb.x, std::fmax(rgb.y, rgb.z));
+        if (mx > 1) rgb = vec3{ rgb.x / mx, rgb.y / mx, rgb.z / mx };
+        return rgb;
+    }
+    void converge_lightning() override {
+        int it = 0;
+        chk(dr_solver_converge(ctx_, threshold_, per_bin_ ? 1 : 0, max_passes_, &it), "dr_solver_converge");
+        numpasses_ += it;
+        refresh();
+    }
+    void increment_lightpass() override {
+        chk(dr_solver_step(ctx_, 1, nullptr), "dr_solver_step");
+        numpasses_++;
+        refresh();
+    }
+    void reset() override {
+        chk(dr_solver_reset(ctx_), "dr_solver_reset");
+        numpasses_ = 0;
+        refresh();
+    }
+    int passes() const override { return numpasses_; }
+    float residual_light() override { float r = 0; chk(dr_solver_step(ctx_, 0, &r), "dr_solver_step"); return r; }
+    const std::vector<float>& lightningvalues() const override { return B_; }
+    int bins() const override { return S_; }
+    dr_info info() override { dr_info i; chk(dr_get_info(ctx_, &i), "dr_get_info"); return i; }
+
+private:
+    void refresh() { chk(dr_solver_read(ctx_, B_.data(), nullptr), "dr_solver_read"); }
+    int method_, max_passes_, N_ = 0, S_ = 0, numpasses_ = 0;
+    float threshold_ = 0;
+    bool per_bin_ = false;
+    MeshS& mesh_;
+    dr_context* ctx_ = nullptr;
+    std::vector<float> B_;
+    std::vector<vec3> xyz_;
+};
+
+}  // namespace
+
+Lightning* Lightning::get_lightning(int method, MeshS& mesh, float& emissionval, std::vector<float> wavelengthsvec,
+                                    bool cuda_enabled, const char* matfile, int device, int max_passes) {
+    if (method < 0 || method > 2)       // the reference falls off the end of the function here (Lightning.h:448-456)
+        throw HipError("lightning method must be 0 (BW), 1 (RGB) or 2 (Spectral)");
+    return new LightningHIP(method, mesh, emissionval, wavelengthsvec, cuda_enabled, matfile, device, max_passes);
+}
+
+}  // namespace daisy

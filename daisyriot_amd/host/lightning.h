@@ -1,0 +1,44 @@
+// lightning.h -- the solver interface of the reference (visual studio/Lightning.h:7-15, 446-457)
+// on top of libdaisyriot_hip.so: same four virtuals, same factory arguments, same convergence
+// thresholds; the radiosity matrix, the passes and the per-patch bin transfer run on the MI355X.
+#pragma once
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/daisyriot_hip.h"
+#include "mesh.h"
+
+namespace daisy {
+
+struct UV { float u, v; };              // visual studio/Defines.h:3-6
+
+// the K visibility samples every pair reuses (OptixPrimeFunctionality.cpp:54-63: u, v*(1-u)),
+// from std::mt19937(seed) instead of srand(time()) so runs are reproducible
+std::vector<UV> make_visibility_samples(int K = DR_RAYS_PER_PATCH, unsigned seed = 20191);
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+class Lightning {
+public:
+    // method 0 = BW, 1 = RGB, 2 = Spectral ([lightning] method); cuda_enabled selects the assembly rule
+    // ([acceleration] cuda_on); matfile: F-matrix cache path or nullptr.
+    // max_passes bounds converge_lightning (the reference has no cap; BW never terminates in closed scenes).
+    static Lightning* get_lightning(int method, MeshS& mesh, float& emissionval, std::vector<float> wavelengthsvec,
+                                    bool cuda_enabled = false, const char* matfile = nullptr, int device = 0,
+                                    int max_passes = 100000);
+    virtual ~Lightning() {}
+    virtual vec3 get_color_of_patch(int) = 0;
+    virtual void converge_lightning() = 0;
+    virtual void increment_lightpass() = 0;
+    virtual void reset() = 0;
+    // additions for a headless host
+    virtual int passes() const = 0;
+    virtual float residual_light() = 0;
+    virtual const std::vector<float>& lightningvalues() const = 0;   // N x S patch-major
+    virtual int bins() const = 0;
+    virtual dr_info info() = 0;
+};
+
+}  // namespace daisy

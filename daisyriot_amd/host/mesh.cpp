@@ -1,0 +1,280 @@
+// mesh.cpp -- OBJ/MTL reader with the semantics the reference gets from tinyobjloader 1.0.6
+// called as LoadObj(..., triangulate=false) (visual studio/MeshS.cpp:22-128), and the material
+// classification of MeshS.cpp:36-66 / Material.cpp:6-100.
+#include "mesh.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+
+namespace daisy {
+
+// ---------------------------------------------------------------------------------------------
+SpectralUpsampler::SpectralUpsampler(const std::string& path) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return;
+    char magic[4];
+    unsigned res = 0;
+    if (std::fread(magic, 4, 1, f) == 1 && std::memcmp(magic, "SPEC", 4) == 0 && std::fread(&res, 4, 1, f) == 1 &&
+        res >= 2 && res <= 1024) {
+        scale_.resize(res);
+        data_.resize((size_t)res * res * res * 9);
+        if (std::fread(scale_.data(), sizeof(float), res, f) == res &&
+            std::fread(data_.data(), sizeof(float), data_.size(), f) == data_.size())
+            res_ = res;
+    }
+    std::fclose(f);
+    if (!res_) { scale_.clear(); data_.clear(); }
+}
+
+// trilinear lookup of the three sigmoid-polynomial coefficients (rgb2spec.cpp:78-121)
+void SpectralUpsampler::fetch(const float rgb[3], float coeff[3]) const {
+    int big = 0;
+    for (int j = 1; j < 3; j++) if (rgb[j] >= rgb[big]) big = j;
+    const int res = (int)res_;
+    const float z = rgb[big], sc = (res - 1) / z;
+    const float x = rgb[(big + 1) % 3] * sc, y = rgb[(big + 2) % 3] * sc;
+    const unsigned xi = std::min((unsigned)x, (unsigned)(res - 2)), yi = std::min((unsigned)y, (unsigned)(res - 2));
+    // interval of z in the (non-uniform) scale table
+    int lo = 0, span = res - 2;
+    while (span > 0) {
+        int half = span >> 1, mid = lo + half + 1;
+        if (scale_[mid] < z) { lo = mid; span -= half + 1; } else span = half;
+    }
+    const unsigned zi = (unsigned)std::min(lo, res - 2);
+    const float x1 = x - xi, x0 = 1.f - x1, y1 = y - yi, y0 = 1.f - y1;
+    const float z1 = (z - scale_[zi]) / (scale_[zi + 1] - scale_[zi]), z0 = 1.f - z1;
+    const size_t dx = 3, dy = 3 * (size_t)res, dz = 3 * (size_t)res * res;
+    size_t o = ((((size_t)big * res + zi) * res + yi) * res + xi) * 3;
+    for (int j = 0; j < 3; j++, o++) {
+        coeff[j] = ((data_[o] * x0 + data_[o + dx] * x1) * y0 + (data_[o + dy] * x0 + data_[o + dy + dx] * x1) * y1) * z0 +
+                   ((data_[o + dz] * x0 + data_[o + dz + dx] * x1) * y0 +
+                    (data_[o + dz + dy] * x0 + data_[o + dz + dy + dx] * x1) * y1) * z1;
+    }
+}
+
+void SpectralUpsampler::spectrum(const vec3& rgb, const std::vector<float>& wl, std::vector<float>& out) const {
+    out.assign(wl.size(), 0.0f);
+    if (rgb.x <= 0 && rgb.y <= 0 && rgb.z <= 0) return;      // black: the table lookup divides by zero
+    if (res_) {
+        float c[3], in[3] = { std::min(rgb.x, 1.f), std::min(rgb.y, 1.f), std::min(rgb.z, 1.f) };
+        for (float& v : in) v = std::max(v, 0.f);
+        fetch(in, c);
+        for (size_t i = 0; i < wl.size(); i++) {             // rgb2spec_eval_precise (rgb2spec.cpp:130-134)
+            float xx = (c[0] * wl[i] + c[1]) * wl[i] + c[2];
+            float yy = 1.f / std::sqrt(xx * xx + 1.f);
+            out[i] = .5f * xx * yy + .5f;
+        }
+        return;
+    }
+    // no table: smooth three-lobe reflectance (same stand-in as daisyriot_amd/scenes.py)
+    static const double mu[3] = { 600.0, 540.0, 450.0 }, sg[3] = { 90.0, 70.0, 80.0 };
+    const double col[3] = { rgb.x, rgb.y, rgb.z };
+    const bool flat = (rgb.x == rgb.y && rgb.y == rgb.z);
+    for (size_t i = 0; i < wl.size(); i++) {
+        double v = 0;
+        if (flat) v = rgb.x;
+        else for (int k = 0; k < 3; k++) { double d = (wl[i] - mu[k]) / sg[k]; v += col[k] * std::exp(-0.5 * d * d); }
+        out[i] = (float)std::min(std::max(v, 0.0), flat ? 1.0 : 0.98);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+Material::Material(const vec3& rgb, const vec3& em, const std::vector<float>& wl, const SpectralUpsampler& up)
+    : rgbcolor(rgb), emission(em), numwavelengths((int)wl.size()) {
+    up.spectrum(rgb, wl, spectral_values);
+    up.spectrum(em, wl, spectral_emission);
+    const int S = numwavelengths;
+    M.assign((size_t)S * S, 0.0f);                            // identity, diagonal = diffuse spectrum
+    for (int i = 0; i < S; i++) M[(size_t)i * S + i] = spectral_values[i];      // Material.cpp:17-20
+}
+
+Material Material::UVLight(const std::vector<float>& wl, const SpectralUpsampler& up) {
+    Material m(vec3{ 0, 0, 0 }, vec3{ 0, 0, 0 }, wl, up);     // MeshS.cpp:45
+    m.kind = MaterialKind::UVLight;
+    for (size_t i = 0; i < wl.size(); i++) {                  // bell curve a*exp(-(x-b)^2/(2c^2)), b=350, c=10 (Material.cpp:69-77)
+        double x = wl[i];
+        m.spectral_emission[i] = (float)(1.0 * std::exp(-1.0 * std::pow(x - 350.0, 2.0) / (2 * std::pow(10.0, 2.0))));
+        m.spectral_values[i] = 0.0f;
+    }
+    // the reference sets M(i,i) = emission[i] with emission a vec3 read out of bounds (Material.cpp:52-54);
+    // a pure emitter reflects nothing: M = 0
+    std::fill(m.M.begin(), m.M.end(), 0.0f);
+    return m;
+}
+
+Material Material::Fluorescent(const vec3& rgb, const vec3& em, const vec3& bl, const std::vector<float>& wl,
+                               const SpectralUpsampler& up) {
+    Material m(rgb, em, wl, up);
+    m.kind = MaterialKind::Fluorescent;
+    m.blacklightcolor = bl;
+    up.spectrum(bl, wl, m.spectral_from_blacklight);
+    const int S = m.numwavelengths;
+    std::fill(m.M.begin(), m.M.end(), 0.0f);                  // M = I ... (Material.cpp:90-100)
+    for (int i = 0; i < S; i++) m.M[(size_t)i * S + i] = 1.0f;
+    for (int i = 0; i < S; i++)
+        if (300.0 < wl[i] && wl[i] < 400.0)                   // ... with the column of every UV bin = blacklight spectrum
+            for (int r = 0; r < S; r++) m.M[(size_t)r * S + i] = m.spectral_from_blacklight[r];
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------------
+MeshS::MeshS(const char* filepath, const char* mtlpath, const std::vector<float>& wl) { loadFromFile(filepath, mtlpath, wl); }
+
+namespace {
+
+struct MtlEntry { std::string name; vec3 Kd{ 0.6f, 0.6f, 0.6f }, Ks{ 0, 0, 0 }, Ke{ 0, 0, 0 }; };
+
+bool read_vec3(std::istringstream& is, vec3& v) {
+    float a = 0, b = 0, c = 0;
+    if (!(is >> a)) return false;
+    if (!(is >> b)) { b = a; c = a; } else if (!(is >> c)) c = 0;
+    v = vec3{ a, b, c };
+    return true;
+}
+
+void load_mtl(const std::string& path, std::vector<MtlEntry>& out, std::string& warn) {
+    std::ifstream f(path.c_str());
+    if (!f.is_open()) { warn += "material file not found: " + path + "\n"; return; }
+    std::string line;
+    while (std::getline(f, line)) {
+        std::istringstream is(line);
+        std::string tok;
+        if (!(is >> tok) || tok[0] == '#') continue;
+        if (tok == "newmtl") { MtlEntry e; is >> e.name; out.push_back(e); }
+        else if (out.empty()) continue;
+        else if (tok == "Kd") read_vec3(is, out.back().Kd);
+        else if (tok == "Ks") read_vec3(is, out.back().Ks);
+        else if (tok == "Ke") read_vec3(is, out.back().Ke);
+    }
+}
+
+// one "v", "v/t", "v//n" or "v/t/n" corner; negative indices count from the end (OBJ spec)
+bool parse_corner(const std::string& tok, int nv, int nn, int& vi, int& ni) {
+    vi = ni = -1;
+    const char* s = tok.c_str();
+    char* e = nullptr;
+    long a = std::strtol(s, &e, 10);
+    if (e == s) return false;
+    vi = a > 0 ? (int)a - 1 : nv + (int)a;
+    if (*e == '/') {
+        e++;
+        if (*e != '/') std::strtol(e, &e, 10);                // texture index, unused
+        if (*e == '/') {
+            e++;
+            const char* s2 = e;
+            long c = std::strtol(s2, &e, 10);
+            if (e != s2) ni = c > 0 ? (int)c - 1 : nn + (int)c;
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+void MeshS::loadFromFile(const char* filepath, const char* mtldir, const std::vector<float>& wl) {
+    *this = MeshS();
+    std::ifstream f(filepath);
+    if (!f.is_open()) { warnings += std::string("cannot open ") + filepath + "\n"; return; }
+    std::string dir = mtldir ? mtldir : "";
+    if (!dir.empty() && dir.back() != '/' && dir.back() != '\\') dir += "/";
+
+    std::vector<MtlEntry> mtl;
+    std::map<std::string, int> mtl_index;
+    std::vector<int> face_mat;
+    int cur_mat = -1;
+    bool polygon_warned = false, normal_warned = false;
+    std::string line;
+    while (std::getline(f, line)) {
+        std::istringstream is(line);
+        std::string tok;
+        if (!(is >> tok) || tok[0] == '#') continue;
+        if (tok == "v") { vec3 v{ 0, 0, 0 }; is >> v.x >> v.y >> v.z; vertices.push_back(v); }
+        else if (tok == "vn") { vec3 v{ 0, 0, 0 }; is >> v.x >> v.y >> v.z; normals.push_back(v); }
+        else if (tok == "mtllib") {
+            std::string name;
+            while (is >> name) {
+                size_t before = mtl.size();
+                load_mtl(dir + name, mtl, warnings);
+                for (size_t k = before; k < mtl.size(); k++) mtl_index[mtl[k].name] = (int)k;
+            }
+        } else if (tok == "usemtl") {
+            std::string name;
+            is >> name;
+            auto it = mtl_index.find(name);
+            cur_mat = it == mtl_index.end() ? -1 : it->second;
+            if (it == mtl_index.end()) warnings += "unknown material " + name + "\n";
+        } else if (tok == "f") {
+            std::vector<std::pair<int, int>> c;
+            std::string ct;
+            while (is >> ct) {
+                int vi, ni;
+                if (parse_corner(ct, (int)vertices.size(), (int)normals.size(), vi, ni)) c.push_back({ vi, ni });
+            }
+            if (c.size() < 3) continue;
+            if (c.size() > 3 && !polygon_warned) {
+                // the reference loads with triangulate=false and then reads indices three at a time,
+                // i.e. it silently assumes triangles; polygons are fan-triangulated here instead
+                warnings += "polygon faces were fan-triangulated\n";
+                polygon_warned = true;
+            }
+            for (size_t k = 1; k + 1 < c.size(); k++) {
+                vertex::TriangleIndex t;
+                t.vertex = ivec3{ c[0].first, c[k].first, c[k + 1].first };
+                t.normal = ivec3{ c[0].second, c[k].second, c[k + 1].second };
+                triangleIndices.push_back(t);
+                face_mat.push_back(cur_mat);
+            }
+        }
+    }
+
+    // faces without vn: the integrand needs a normal per corner (triangle_math.cpp:23-29) -> geometric normal
+    for (auto& t : triangleIndices) {
+        if (t.normal.x >= 0 && t.normal.y >= 0 && t.normal.z >= 0) continue;
+        if (!normal_warned) { warnings += "faces without normals got their geometric normal\n"; normal_warned = true; }
+        const vec3 &a = vertices[t.vertex.x], &b = vertices[t.vertex.y], &c = vertices[t.vertex.z];
+        vec3 e1{ b.x - a.x, b.y - a.y, b.z - a.z }, e2{ c.x - a.x, c.y - a.y, c.z - a.z };
+        vec3 n{ e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x };
+        float l = std::sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
+        if (l > 0) { n.x /= l; n.y /= l; n.z /= l; }
+        normals.push_back(n);
+        int id = (int)normals.size() - 1;
+        t.normal = ivec3{ id, id, id };
+    }
+
+    // materials, classified as MeshS.cpp:36-66 does
+    SpectralUpsampler up;
+    for (const MtlEntry& e : mtl) {
+        const bool blacklightsource = (e.Ke.x + e.Ke.y + e.Ke.z > 0) && (e.Kd.x + e.Kd.y + e.Kd.z == 0.0f);
+        const bool fluorescent = (e.Ks.x + e.Ks.y + e.Ks.z > 0.0f);
+        Material m = blacklightsource ? Material::UVLight(wl, up)
+                     : fluorescent    ? Material::Fluorescent(e.Kd, e.Ke, e.Ks, wl, up)
+                                      : Material(e.Kd, e.Ke, wl, up);
+        m.name = e.name;
+        materials.push_back(m);
+    }
+    bool need_default = false;
+    for (int m : face_mat) need_default = need_default || m < 0;
+    if (need_default) {      // tinyobj reports -1 and the reference would index materials[-1]
+        Material m(vec3{ 0.6f, 0.6f, 0.6f }, vec3{ 0, 0, 0 }, wl, up);
+        m.name = "(default)";
+        materials.push_back(m);
+        warnings += "faces without a material use a default grey\n";
+    }
+    materialIndexPerTriangle.resize(face_mat.size());
+    for (size_t k = 0; k < face_mat.size(); k++) materialIndexPerTriangle[k] = face_mat[k] < 0 ? (int)materials.size() - 1 : face_mat[k];
+
+    trianglesPerVertex.assign(vertices.size(), {});
+    for (size_t t = 0; t < triangleIndices.size(); t++)
+        for (int k = 0; k < 3; k++) {
+            int v = triangleIndices[t].vertex[k];
+            if (v >= 0 && v < (int)vertices.size()) trianglesPerVertex[v].push_back((int)t);
+        }
+    numtriangles = (int)triangleIndices.size();
+}
+
+}  // namespace daisy

@@ -293,3 +293,18 @@ def write_obj(scene, obj_path, mtl_name="scene.mtl"):
             a, b, c = scene.tri_v[t] + 1
             na, nb, nc = scene.tri_n[t] + 1
             f.write("f %d//%d %d//%d %d//%d\n" % (a, na, b, nb, c, nc))
+
+
+def write_mtl(scene, mtl_path, rgb=None, emit_rgb=None, blacklight=None):
+    """MTL with the three keys the reference reads (vs/MeshS.cpp:37-39): Kd diffuse, Ke emission,
+    Ks = the "blacklight" colour that marks a fluorescent material.  rgb / emit_rgb default to the
+    scene's S=3 reflectance / emission."""
+    rgb = scene.rho if rgb is None else rgb
+    emit_rgb = scene.emit if emit_rgb is None else emit_rgb
+    with open(mtl_path, "w") as f:
+        for m, name in enumerate(scene.material_names):
+            f.write("newmtl %s\n" % name)
+            f.write("Kd %.9g %.9g %.9g\n" % tuple(rgb[m][:3]))
+            f.write("Ke %.9g %.9g %.9g\n" % tuple(emit_rgb[m][:3]))
+            ks = (0, 0, 0) if blacklight is None else blacklight[m]
+            f.write("Ks %.9g %.9g %.9g\n\n" % tuple(ks))

@@ -1,0 +1,102 @@
+"""End to end through the C++ host: config.ini + .obj/.mtl -> MeshS -> Lightning (factory,
+converge, F cache) -> per-patch radiance, on the GPU, against the Python/ctypes route and the
+oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from daisyriot_amd import api, scenes
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "daisyriot_amd", "lib", "daisyriot_cli")
+HOST = os.path.join(ROOT, "daisyriot_amd", "lib", "libdaisyriot_host.so")
+
+
+def _host_uv():
+    C.CDLL(api.LIB_PATH, mode=C.RTLD_GLOBAL)
+    L = C.CDLL(HOST)
+    uv = np.zeros((50, 2), np.float32)
+    L.drh_visibility_samples(50, C.c_uint(20191), uv.ctypes.data_as(C.c_void_p))
+    return uv
+
+
+def _write_scene(tmp_path, n, method, cuda_on):
+    sc = scenes.cornell_box(n, S=3)
+    scenes.write_obj(sc, str(tmp_path / "box.obj"), "box.mtl")
+    scenes.write_mtl(sc, str(tmp_path / "box.mtl"))
+    (tmp_path / "config.ini").write_text(
+        "[window]\nwidth = 800\nheight = 600\n[filepaths]\nscene = %s\nmtl_dir = %s/\n"
+        "[drawing]\nradiosityRendering = true\n[lightning]\nemission_value = 7.0 ; per scene\nmethod = %d\n"
+        "[acceleration]\ncuda_on = %s\n" % (tmp_path / "box.obj", tmp_path, method, "true" if cuda_on else "false"))
+    return sc
+
+
+def _run(tmp_path, *extra):
+    out = tmp_path / "out.csv"
+    r = subprocess.run([CLI, str(tmp_path / "config.ini"), "--out", str(out)] + list(extra),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    data = np.loadtxt(out, delimiter=",", skiprows=1)
+    return r.stdout, data
+
+
+@pytest.mark.parametrize("cuda_on", [True, False])
+def test_rgb_scene_through_the_cli(tmp_path, cuda_on):
+    sc = _write_scene(tmp_path, 420, 1, cuda_on)
+    stdout, data = _run(tmp_path, "--no-matfile")
+    assert "Number of triangles: 420" in stdout
+    B_cli = data[:, 4:7].astype(np.float32)
+    assert np.array_equal(data[:, 1:4].astype(np.float32), B_cli)          # RGB colour = B (Lightning.h:332-334)
+    # same thing through ctypes, and through the oracle
+    uv = _host_uv()
+    E = sc.emission(7.0)
+    rule = api.RULE_INTEGRAND if cuda_on else api.RULE_RECIPROCITY
+    with api.Context(0) as c:
+        c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+        c.assemble(uv, rule=rule)
+        F = c.read_rows(0, sc.N)
+        c.solver_init(E, sc.M, sc.mat_of_patch)
+        it = c.converge(1e-4, per_bin=True, max_iters=100000)
+        B_py, _ = c.read()
+    assert ("Number of light passes %d." % it) in stdout
+    assert np.allclose(B_cli, B_py, rtol=1e-6, atol=1e-9)
+    Fo, _, _ = ob.assemble_rows(ob.Mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n), uv, rule=rule, bvh=True, want_vis=False)
+    assert np.array_equal(F.view(np.uint32), Fo.view(np.uint32))
+    it_o, _, B_o = ob.converge(Fo, sc.M, sc.mat_of_patch, E, 1e-4, True, 100000)
+    assert it_o == it
+    assert (np.abs(B_cli - B_o) / np.abs(B_o).max(axis=0)).max() < 1e-4      # north_star's bar
+
+
+def test_f_cache_round_trip_and_extra_passes(tmp_path):
+    _write_scene(tmp_path, 300, 1, True)
+    out1, d1 = _run(tmp_path)
+    assert "Loaded & Serialized matrix" in out1 and os.path.exists(tmp_path / "box")
+    # header of the reference's format (Lightning.h:38-46): rows, cols, nnz, outerSize, innerSize
+    hdr = np.fromfile(tmp_path / "box", dtype=np.int32, count=5)
+    assert hdr[0] == hdr[1] == hdr[3] == hdr[4] == 300 and 0 < hdr[2] < 300 * 300
+    out2, d2 = _run(tmp_path)
+    assert "Deserialized matrix" in out2
+    assert np.array_equal(d1, d2)
+    out3, d3 = _run(tmp_path, "--passes", "3")                                # three presses of 'L'
+    assert (d3[:, 4:] >= d2[:, 4:]).all() and (d3[:, 4:] > d2[:, 4:]).any()
+
+
+def test_spectral_and_bw_methods_run(tmp_path):
+    _write_scene(tmp_path, 300, 2, True)
+    out, d = _run(tmp_path, "--no-matfile", "--passes", "4")
+    assert d.shape == (300, 4 + 9)                                            # nine bins (main.cpp:94)
+    assert np.isfinite(d).all() and (d[:, 1:4] <= 1 + 1e-6).all()             # display colour normalised (Lightning.h:177-180)
+    assert "Number of light passes 4." in out                                 # 63 < 200: converge takes no pass
+    # BW has no reflectance (Lightning.h:419-424) and never converges in a closed room: cap it
+    ini = (tmp_path / "config.ini").read_text().replace("method = 2", "method = 0\nmax_passes = 12")
+    (tmp_path / "config.ini").write_text(ini)
+    out, d = _run(tmp_path, "--no-matfile")
+    assert d.shape == (300, 5) and np.isfinite(d).all() and "Number of light passes 12." in out
+    r = subprocess.run([CLI, str(tmp_path / "missing.ini")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Can't load" in r.stdout

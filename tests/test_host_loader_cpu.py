@@ -1,0 +1,176 @@
+"""The C++ host above the C ABI (daisyriot_amd/host): config.ini reader and MeshS / Material
+loader keep the reference's loading surface.  CPU only; the library is
+reached through its small C view (host_capi.cpp)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from daisyriot_amd import scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "daisyriot_amd", "lib", "libdaisyriot_host.so")
+REF_SCENES = "/root/reference/example_scenes"
+WL9 = np.arange(200.0, 601.0, 50.0, dtype=np.float32)
+
+
+@pytest.fixture(scope="module")
+def host():
+    C.CDLL(os.path.join(ROOT, "daisyriot_amd", "lib", "libdaisyriot_hip.so"), mode=C.RTLD_GLOBAL)
+    L = C.CDLL(HOST)
+    L.drh_mesh_load.restype = C.c_void_p
+    L.drh_mesh_load.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int]
+    L.drh_mesh_free.argtypes = [C.c_void_p]
+    L.drh_mesh_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+    L.drh_mesh_warnings.restype = C.c_char_p
+    L.drh_mesh_warnings.argtypes = [C.c_void_p]
+    L.drh_mesh_copy.argtypes = [C.c_void_p] * 6
+    L.drh_mesh_materials.argtypes = [C.c_void_p] * 7
+    L.drh_vertex_fanout.argtypes = [C.c_void_p, C.c_int]
+    for f in ("drh_ini_open", "drh_ini_parse"):
+        getattr(L, f).restype = C.c_void_p
+        getattr(L, f).argtypes = [C.c_char_p]
+    L.drh_ini_free.argtypes = [C.c_void_p]
+    L.drh_ini_error.argtypes = [C.c_void_p]
+    L.drh_ini_get.restype = C.c_char_p
+    L.drh_ini_get.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.drh_ini_integer.restype = C.c_long
+    L.drh_ini_integer.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_long]
+    L.drh_ini_real.restype = C.c_double
+    L.drh_ini_real.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_double]
+    L.drh_ini_boolean.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
+    L.drh_visibility_samples.argtypes = [C.c_int, C.c_uint, C.c_void_p]
+    return L
+
+
+def load(host, obj, mtl_dir, wl=WL9):
+    wl = np.ascontiguousarray(wl, np.float32)
+    h = host.drh_mesh_load(obj.encode(), mtl_dir.encode(), wl.ctypes.data_as(C.c_void_p), wl.size)
+    V, Nn, N, nm = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    host.drh_mesh_counts(h, C.byref(V), C.byref(Nn), C.byref(N), C.byref(nm))
+    V, Nn, N, nm, S = V.value, Nn.value, N.value, nm.value, wl.size
+    out = dict(vertices=np.zeros((V, 3), np.float32), normals=np.zeros((Nn, 3), np.float32),
+               tri_v=np.zeros((N, 3), np.int32), tri_n=np.zeros((N, 3), np.int32), mat=np.zeros(N, np.int32))
+    host.drh_mesh_copy(h, *[out[k].ctypes.data_as(C.c_void_p) for k in ("vertices", "normals", "tri_v", "tri_n", "mat")])
+    m = dict(kind=np.zeros(nm, np.int32), rgb=np.zeros((nm, 3), np.float32), emission=np.zeros((nm, 3), np.float32),
+             spectral_values=np.zeros((nm, S), np.float32), spectral_emission=np.zeros((nm, S), np.float32),
+             M=np.zeros((nm, S, S), np.float32))
+    host.drh_mesh_materials(h, *[m[k].ctypes.data_as(C.c_void_p) for k in
+                                 ("kind", "rgb", "emission", "spectral_values", "spectral_emission", "M")])
+    out.update(m)
+    out["warnings"] = host.drh_mesh_warnings(h).decode()
+    out["fanout0"] = host.drh_vertex_fanout(h, int(out["tri_v"][0, 0])) if N else 0
+    host.drh_mesh_free(h)
+    return out
+
+
+INI_TEXT = b"""; Example config file for DaisyRiot application
+
+[window]             ; Window configuration
+width = 800
+height = 600
+
+[filepaths]\t\t\t; Necesarry directories
+scene = example_scenes/cornellbox_blacklight.obj
+mtl_dir = example_scenes/
+
+[drawing]
+radiosityRendering = true
+antiAliasing = true
+supersampling = 4
+
+[lightning]\t\t\t; Lightning configuration
+emission_value = 7.0 ; Best to adjust this value per scene
+method = 2\t\t\t; 0 = BW, 1 = RGB, 2 = Spectral
+
+[acceleration]
+cuda_on = true
+hexval : 0x10
+"""
+
+
+def test_ini_reader_reads_the_reference_keys(host, tmp_path):
+    p = tmp_path / "config.ini"
+    p.write_bytes(INI_TEXT)
+    for h in (host.drh_ini_open(str(p).encode()), host.drh_ini_parse(INI_TEXT)):
+        assert host.drh_ini_error(h) == 0
+        assert host.drh_ini_integer(h, b"window", b"width", -1) == 800                    # main.cpp:68
+        assert host.drh_ini_real(h, b"lightning", b"emission_value", -1) == 7.0          # inline comment cut
+        assert host.drh_ini_integer(h, b"LIGHTNING", b"Method", 0) == 2                  # case-insensitive
+        assert host.drh_ini_boolean(h, b"acceleration", b"cuda_on", 0) == 1
+        assert host.drh_ini_get(h, b"filepaths", b"scene", b"UNKNOWN") == b"example_scenes/cornellbox_blacklight.obj"
+        assert host.drh_ini_get(h, b"filepaths", b"nope", b"UNKNOWN") == b"UNKNOWN"
+        assert host.drh_ini_integer(h, b"acceleration", b"hexval", 0) == 16
+        assert host.drh_ini_boolean(h, b"drawing", b"supersampling", 1) == 1              # "4" is not a boolean -> default
+        host.drh_ini_free(h)
+    h = host.drh_ini_open(b"/nonexistent/config.ini")
+    assert host.drh_ini_error(h) == -1                                                   # main.cpp:64-67 prints and exits
+    host.drh_ini_free(h)
+    h = host.drh_ini_parse(b"[a]\nok = 1\nthis line has no separator\nx = 2\n")
+    assert host.drh_ini_error(h) == 3 and host.drh_ini_integer(h, b"a", b"x", 0) == 2
+    host.drh_ini_free(h)
+
+
+def test_obj_round_trip(host, tmp_path):
+    sc = scenes.cornell_box(500, S=3)
+    scenes.write_obj(sc, str(tmp_path / "box.obj"), "box.mtl")
+    scenes.write_mtl(sc, str(tmp_path / "box.mtl"))
+    got = load(host, str(tmp_path / "box.obj"), str(tmp_path) + "/")
+    assert got["warnings"] == ""
+    assert np.array_equal(got["vertices"], sc.vertices) and np.array_equal(got["normals"], sc.normals)
+    assert np.array_equal(got["tri_v"], sc.tri_v) and np.array_equal(got["tri_n"], sc.tri_n)
+    assert np.array_equal(got["mat"], sc.mat_of_patch)
+    assert np.array_equal(got["rgb"], sc.rho) and np.array_equal(got["emission"], sc.emit)
+    assert got["fanout0"] >= 1
+    assert (got["kind"] == 0).all()
+
+
+def test_obj_dialects_and_repairs(host, tmp_path):
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 1 0 0\nKe 0 0 0\nnewmtl lamp\nKd 0 0 0\nKe 1 1 1\n"
+                                    "newmtl glow\nKd 0.5 0.5 0.5\nKs 0 0.8 1\n")
+    (tmp_path / "t.obj").write_text(
+        "mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\n"
+        "f 1//1 2//1 3//1\n"                  # no material yet -> default grey
+        "usemtl a\nf 1/1/1 2/1/1 3/1/1 4/1/1\n"  # quad -> two triangles
+        "usemtl lamp\nf -4//-1 -3//-1 -2//-1\n"  # negative (relative) indices
+        "usemtl glow\nf 1 2 4\n")              # no normals -> geometric normal
+    got = load(host, str(tmp_path / "t.obj"), str(tmp_path))
+    assert got["tri_v"].tolist() == [[0, 1, 2], [0, 1, 2], [0, 2, 3], [0, 1, 2], [0, 1, 3]]
+    assert got["mat"].tolist() == [3, 0, 0, 1, 2]
+    assert got["kind"].tolist() == [0, 1, 2, 0]                 # plain, UV light, fluorescent, default
+    assert np.allclose(got["normals"][got["tri_n"][4, 0]], [0, 0, 1])
+    for w in ("fan-triangulated", "geometric normal", "default grey"):
+        assert w in got["warnings"]
+    # UV lamp (Material.cpp:47-78): bell curve around 350 nm, reflects nothing
+    assert got["spectral_emission"][1].argmax() == 3 and np.all(got["M"][1] == 0)
+    # fluorescent (Material.cpp:90-100): identity with the 350 nm column replaced
+    Mf = got["M"][2]
+    assert np.allclose(np.diag(Mf)[[0, 1, 2, 4, 5, 6, 7, 8]], 1.0)
+    assert np.all(Mf[:, 3] <= 0.98 + 1e-6) and Mf[:, 3].max() > 0.1
+    off = Mf.copy()
+    off[:, 3] = 0
+    np.fill_diagonal(off, 0)
+    assert np.all(off == 0)
+    # plain (Material.cpp:17-20): M = diag(diffuse spectrum)
+    assert np.allclose(got["M"][0], np.diag(got["spectral_values"][0]))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SCENES), reason="reference example scenes not present on this box")
+def test_reference_example_scenes_load_unchanged(host):
+    got = load(host, REF_SCENES + "/cornellbox_blacklight.obj", REF_SCENES + "/")
+    assert got["tri_v"].shape[0] == 7712 and got["vertices"].shape[0] == 4360 and got["normals"].shape[0] == 304
+    assert got["kind"].tolist() == [1, 2, 2, 0]          # Blacklight, Blacklight_Pink, Blacklight_blue, white (MeshS.cpp:41-63)
+    assert got["warnings"] == ""
+    got = load(host, REF_SCENES + "/colorballs.obj", REF_SCENES + "/")
+    assert got["tri_v"].shape[0] == 6400 and got["vertices"].shape[0] == 3373 and got["normals"].shape[0] == 2551
+    assert got["rgb"].shape[0] == 5 and (got["emission"].sum(axis=1) > 0).sum() == 4      # 4 coloured emitters + white
+
+
+def test_visibility_samples_follow_the_reference_formula(host):
+    uv = np.zeros((50, 2), np.float32)
+    host.drh_visibility_samples(50, 20191, uv.ctypes.data_as(C.c_void_p))
+    assert (uv >= 0).all() and (uv[:, 0] < 1).all() and (uv.sum(axis=1) <= 1 + 1e-6).all()
+    uv2 = np.zeros((50, 2), np.float32)
+    host.drh_visibility_samples(50, 20191, uv2.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(uv, uv2)
