@@ -67,6 +67,8 @@ struct dr_context {
     float *d_M = nullptr, *d_E = nullptr, *d_B = nullptr, *d_R[2] = { nullptr, nullptr };
     int* d_mat = nullptr;
     double* d_sums = nullptr;
+    float* d_Gpart = nullptr;
+    int ksplit = 1;
     int cur = 0;
     bool have_solver = false;
     Comm comm;
@@ -88,7 +90,7 @@ void free_F(dr_context* c) {
 }
 void free_solver(dr_context* c) {
     hipFree(c->d_M); hipFree(c->d_E); hipFree(c->d_B); hipFree(c->d_R[0]); hipFree(c->d_R[1]);
-    hipFree(c->d_mat); hipFree(c->d_sums);
+    hipFree(c->d_mat); hipFree(c->d_sums); hipFree(c->d_Gpart); c->d_Gpart = nullptr;
     c->d_M = c->d_E = c->d_B = c->d_R[0] = c->d_R[1] = nullptr; c->d_mat = nullptr; c->d_sums = nullptr;
     c->have_solver = false;
 }
@@ -143,6 +145,7 @@ int sweep_once(dr_context* c) {
     p.N = c->N; p.S = c->S; p.rpr = c->rpr; p.world = c->world; p.row0 = c->row0; p.nrows = c->nrows;
     p.ldF = c->ldF; p.F = c->d_F; p.Rin = c->d_R[c->cur]; p.Rout = c->d_R[c->cur ^ 1]; p.rank = c->rank;
     p.B = c->d_B; p.M = c->d_M; p.mat = c->d_mat; p.n_mat = c->n_mat;
+    p.skew = 0; p.ksplit = c->ksplit; p.Gpart = c->d_Gpart;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profile) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -162,7 +165,7 @@ int sweep_once(dr_context* c) {
     }
     HIPCHK(launch_sweep(c->stream, p));
     if (c->profile) HIPCHK(hipEventRecord(e1, c->stream));
-    if (c->world > 1) {
+    if (c->comm.comm) {
         std::string err = comm_allgather_inplace(c->comm, c->d_R[c->cur ^ 1], (size_t)c->S * c->rpr, c->stream);
         if (!err.empty()) return fail(DR_ERR_COMM, "%s", err.c_str());
     }
@@ -410,7 +413,9 @@ int dr_solver_init(dr_context* c, int S, const float* E, const float* M, int n_m
     for (int i = 0; i < c->N; i++)
         if (mat_of_patch[i] < 0 || mat_of_patch[i] >= n_mat)
             return fail(DR_ERR_INVALID, "material index %d of patch %d out of range [0,%d)", mat_of_patch[i], i, n_mat);
-    if (c->world > 1 && !c->comm.comm) return fail(DR_ERR_STATE, "world=%d but dr_comm_init has not been called", c->world);
+    // DR_NO_COMM=1: time one rank's shard alone (its residual chunks of other ranks stay at E)
+    if (c->world > 1 && !c->comm.comm && !getenv("DR_NO_COMM"))
+        return fail(DR_ERR_STATE, "world=%d but dr_comm_init has not been called", c->world);
     HIPCHK(hipStreamSynchronize(c->stream));
     free_solver(c);
     c->S = S; c->n_mat = n_mat;
@@ -422,6 +427,8 @@ int dr_solver_init(dr_context* c, int S, const float* E, const float* M, int n_m
     HIPCHK(hipMalloc(&c->d_B, sizeof(float) * (size_t)S * c->rpr));
     HIPCHK(hipMalloc(&c->d_mat, sizeof(int) * (size_t)c->rpr));
     HIPCHK(hipMalloc(&c->d_sums, sizeof(double) * DR_MAX_BINS));
+    c->ksplit = sweep_ksplit(c->nrows, S, (int)c->ldF);
+    if (c->ksplit > 1) HIPCHK(hipMalloc(&c->d_Gpart, sizeof(float) * (size_t)c->ksplit * std::max(c->nrows, 1) * S));
     float* tmp = nullptr;
     HIPCHK(hipMalloc(&tmp, sizeof(float) * (size_t)c->N * S));
     HIPCHK(hipMemcpyAsync(tmp, E, sizeof(float) * (size_t)c->N * S, hipMemcpyHostToDevice, c->stream));

@@ -67,6 +67,8 @@ struct SweepParams {
     const int* mat;       // [rpr] local material index
     int n_mat;
     int skew;         // per-block start-tile multiplier (0 = every block starts at column 0)
+    int ksplit;       // column splits (1 = fused epilogue; >1 = partial sums + k_sweep_epilogue)
+    float* Gpart;     // [ksplit][nrows][S] partial F*R sums when ksplit > 1
 };
 
 // launchers implemented in the .hip files
@@ -77,6 +79,7 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float scen
                       TriRec* tri_sorted /* N + LEAF_MAX */, int* n_nodes_out);
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p);
 hipError_t launch_sweep(hipStream_t st, const SweepParams& p);
+int sweep_ksplit(int nrows, int S, int total_cols);
 hipError_t launch_colsums(hipStream_t st, const float* R, int world, int S, int rpr, double* sums);
 // layout conversion between the ABI's patch-major N x S and the device's bin-major chunks
 hipError_t launch_scatter_rows(hipStream_t st, const float* src_NxS, int N, int S, int rpr, int world,

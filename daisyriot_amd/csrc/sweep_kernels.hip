@@ -19,7 +19,10 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // S bins, RR rows per wave, NW waves per block, CPL float4 column groups per lane per row
 // and tile (tile = 256*CPL columns), NT = non-temporal F loads (F is streamed once; keep
 // the residual, which every block re-reads, resident in L2 instead).
-template <int S, int RR, int NW, int CPL, bool NT, int OCC>
+// SPLIT: the columns are cut into gridDim.y ranges (small row shards would otherwise leave most
+// CUs with one block or none); each block then writes its partial sums and k_sweep_epilogue adds
+// them in a fixed order and applies the bin transfer.
+template <int S, int RR, int NW, int CPL, bool NT, int OCC, bool SPLIT>
 __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
     constexpr int TC = 256 * CPL;
     __shared__ __attribute__((aligned(16))) float sR[2][S][TC];
@@ -29,7 +32,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rbase = (blockIdx.x * NW + wave) * RR;       // first local row of this wave (uniform)
-    const int ntiles = (P.world * P.rpr) / TC;
+    const int ntiles_all = (P.world * P.rpr) / TC;
+    const int ntiles = SPLIT ? ntiles_all / (int)gridDim.y : ntiles_all;      // tiles of this block
+    const int tile0 = SPLIT ? (int)blockIdx.y * ntiles : 0;
     const int tiles_per_chunk = P.rpr / TC;
 
     // wave-uniform row bases (SGPRs); rows past the shard are clamped for loading, masked at the end
@@ -47,7 +52,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
     constexpr int NV4 = S * 64 * CPL;
     constexpr int R4_PER_THREAD = (NV4 + NW * 64 - 1) / (NW * 64);
     v4f rreg[R4_PER_THREAD];
-    auto load_rtile = [&](int t) {
+    auto load_rtile = [&](int tl) {
+        const int t = tile0 + tl;
         const int chunk = t / tiles_per_chunk;
         const int l0 = (t - chunk * tiles_per_chunk) * TC;
         const float* base = P.Rin + (size_t)chunk * S * P.rpr + l0;
@@ -70,7 +76,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
             }
         }
     };
-    auto load_f = [&](int t, v4f (&dst)[RR][CPL]) {
+    auto load_f = [&](int tl, v4f (&dst)[RR][CPL]) {
+        const int t = tile0 + tl;
 #pragma unroll
         for (int r = 0; r < RR; r++)
 #pragma unroll
@@ -136,6 +143,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
     }
     __syncthreads();
 
+    if (SPLIT) {
+        for (int e = lane; e < RR * S; e += 64) {
+            const int r = e / S, s = e % S;
+            const int row = rbase + r;
+            if (row < P.nrows) P.Gpart[((size_t)blockIdx.y * P.nrows + row) * S + s] = sG[wave][r][s];
+        }
+        return;
+    }
     // epilogue: per-patch S x S bin transfer, residual out, B += residual
     for (int e = lane; e < RR * S; e += 64) {
         const int so = e / RR, r = e % RR;          // consecutive lanes -> consecutive rows of one bin
@@ -152,12 +167,59 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
     }
 }
 
+// sums the column-split partials in split order and applies M (one thread per row and output bin)
+template <int S>
+__global__ void k_sweep_epilogue(SweepParams P) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= P.nrows * S) return;
+    const int so = x / P.nrows, row = x % P.nrows;      // consecutive threads -> consecutive rows
+    float G[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) G[s] = 0.0f;
+    for (int k = 0; k < P.ksplit; k++) {
+        const float* g = P.Gpart + ((size_t)k * P.nrows + row) * S;
+#pragma unroll
+        for (int s = 0; s < S; s++) G[s] += g[s];
+    }
+    const float* Mi = P.M + (size_t)P.mat[row] * S * S + so * S;
+    float v = 0.0f;
+#pragma unroll
+    for (int s = 0; s < S; s++) v = fmaf(Mi[s], G[s], v);
+    P.Rout[((size_t)P.rank * S + so) * P.rpr + row] = v;
+    float* b = P.B + (size_t)so * P.rpr + row;
+    *b = *b + v;
+}
+
 template <int S, int RR, int NW, int CPL, bool NT, int OCC = 1>
 static hipError_t launch_cfg(hipStream_t st, const SweepParams& p) {
     const int rows_per_block = RR * NW;
-    dim3 grid((p.nrows + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC>), grid, dim3(NW * 64), 0, st, p);
+    dim3 grid((p.nrows + rows_per_block - 1) / rows_per_block, p.ksplit);
+    if (p.ksplit > 1) {
+        hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC, true>), grid, dim3(NW * 64), 0, st, p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_sweep_epilogue<S>), dim3((p.nrows * S + 255) / 256), dim3(256), 0, st, p);
+    } else {
+        hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC, false>), grid, dim3(NW * 64), 0, st, p);
+    }
     return hipGetLastError();
+}
+
+// How many column ranges to cut the sweep into.  With 512 or more row blocks (2 per CU) the fused
+// single pass is fastest; below that, cut columns until there are about 1024 blocks, each block
+// keeping at least 16 tiles; the count must divide the tile count.  Measured at N = 65 536 on one
+// MI355X (profiles/r01/sweep_shards.md): 8192 rows 0.437 ms unsplit -> 0.342 ms with 4 ranges.
+int sweep_ksplit(int nrows, int S, int total_cols) {
+    const int rr = (S <= 8) ? 8 : 4;
+    const int row_blocks = (nrows + rr * 4 - 1) / (rr * 4);
+    const int ntiles = total_cols / 256;
+    static int forced = -2;
+    if (forced == -2) { const char* e = getenv("DR_SWEEP_KSPLIT"); forced = e ? atoi(e) : -1; }
+    int want = forced > 0 ? forced : (row_blocks >= 512 ? 1 : (1024 + row_blocks - 1) / (row_blocks > 0 ? row_blocks : 1));
+    int ks = 1;
+    for (int k = 1; k <= want && k <= 64; k++)
+        if (ntiles % k == 0 && ntiles / k >= (forced > 0 ? 1 : 16)) ks = k;
+    return ks;
 }
 
 template <int S>
