@@ -25,6 +25,8 @@ namespace dr {
 // fp32 helpers in glm 0.9.8.4's operation order (func_geometric.inl)
 // ---------------------------------------------------------------------------------------
 struct f3 { float x, y, z; };
+typedef float v8f __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f3 ld3(const float* p) { return f3{ p[0], p[1], p[2] }; }
 __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{ a.x + b.x, a.y + b.y, a.z + b.z }; }
 __device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
@@ -469,36 +471,53 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
                 }
                 const f3 inv = f3{ safe_inv(dn.x), safe_inv(dn.y), safe_inv(dn.z) };
                 const f3 noi = f3{ -(org.x * inv.x), -(org.y * inv.y), -(org.z * inv.z) };
-                int node = 0;
-                // every step moves forward in pre-order, so n_nodes steps bound the walk even
-                // if the node array were corrupt (no wave may spin forever on the device)
-                for (int guard = 0; guard < P.n_nodes && node < P.n_nodes; guard++) {
-                    if (__ballot(alive) == 0ull) break;
-                    const BvhNode nd = P.bvh[node];
-                    n_visit++;
-                    const bool hb = alive && box_hit(nd, noi, inv, tmax);
-                    if (__ballot(hb) == 0ull) { node = __builtin_amdgcn_readfirstlane(nd.skip); continue; }
-                    const int leaf = __builtin_amdgcn_readfirstlane(nd.tri);
-                    if (leaf >= 0) {
-                        n_leaf++;
-                        const int first = leaf >> 3, cnt = (leaf & 7) + 1;
-                        // fixed-width fetch (the array is padded) so the scalar loads issue together
-                        TriRec Tk[LEAF_MAX];
-#pragma unroll
-                        for (int c = 0; c < LEAF_MAX; c++) Tk[c] = P.tri_sorted[first + c];
-#pragma unroll
-                        for (int c = 0; c < LEAF_MAX; c++) {
-                            const int tk = Tk[c].id;
-                            if (c < cnt && tk != hi) {
-                                float tt;
-                                if (hb && tri_hit(org, dn, ld3(Tk[c].a), ld3(Tk[c].e1), ld3(Tk[c].e2), tt)) {
-                                    // closest hit is not `hi`: something nearer, or an equal-t hit of lower id
-                                    if (tt < tmax || (tt == tmax && tk < hi)) alive = false;
-                                }
-                            }
-                        }
-                    }
+                // Walk the threaded BVH with a wave-uniform node index.  The loop is scalar-unit
+                // heavy (branches, masks, address arithmetic), so it is kept minimal: one node load,
+                // one slab test, one ballot per step; the "any lane still alive" test only runs after a
+                // leaf could have retired lanes.  Every step moves forward in pre-order, so the node
+                // count bounds the walk even if the node array were corrupt.
+                const unsigned n_nodes = (unsigned)P.n_nodes;
+                unsigned node = (__ballot(alive) == 0ull) ? n_nodes : 0u;
+                while (node < n_nodes) {
+                    // the whole 32-byte node in one scalar load (field-wise loads would chain latencies)
+                    // (float vector + __float_as_int: __builtin_bit_cast on a vector ELEMENT reads element 0)
+                    const v8f raw = *reinterpret_cast<const v8f*>(P.bvh + node);
+                    BvhNode nd;
+                    nd.lo[0] = raw[0]; nd.lo[1] = raw[1]; nd.lo[2] = raw[2];
+                    nd.hi[0] = raw[3]; nd.hi[1] = raw[4]; nd.hi[2] = raw[5];
+                    const int nd_skip = __builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
+                    const int leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
+                    if (STATS) n_visit++;
+                    // no short-circuit: the slab test runs for every lane, dead ones are masked after
+                    const bool hb = box_hit(nd, noi, inv, tmax) & alive;
+                    if (__ballot(hb) == 0ull) { node = max((unsigned)nd_skip, node + 1u); continue; }
                     node = node + 1;
+                    if (leaf < 0) continue;
+                    if (STATS) n_leaf++;
+                    const int first = leaf >> 3, cnt = (leaf & 7) + 1;
+                    // Branch-free leaf: all LEAF_MAX records are fetched together (the array is padded
+                    // with degenerate triangles, which never hit) and tested; a record beyond the
+                    // leaf's count is masked.  The destination itself needs no exclusion: its t equals
+                    // tmax bit for bit and its id is not lower than its own.
+                    const v4f* tp = reinterpret_cast<const v4f*>(P.tri_sorted + first);
+                    v4f q[3 * LEAF_MAX];
+#pragma unroll
+                    for (int c = 0; c < 3 * LEAF_MAX; c++) q[c] = tp[c];
+                    bool blocked = false;
+#pragma unroll
+                    for (int c = 0; c < LEAF_MAX; c++) {
+                        const v4f A = q[3 * c], B = q[3 * c + 1], C3 = q[3 * c + 2];
+                        const f3 ta = f3{ A[0], A[1], A[2] };
+                        const f3 te1 = f3{ A[3], B[0], B[1] };
+                        const f3 te2 = f3{ B[2], B[3], C3[0] };
+                        const int tk = __builtin_amdgcn_readfirstlane(__float_as_int(C3[1]));
+                        float tt;
+                        const bool h = tri_hit(org, dn, ta, te1, te2, tt);
+                        // closest hit is not `hi`: something nearer, or an equal-t hit of lower id
+                        blocked = blocked | (h & (c < cnt) & ((tt < tmax) | ((tt == tmax) & (tk < hi))));
+                    }
+                    alive = alive & !(blocked & hb);
+                    if (__ballot(alive) == 0ull) break;
                 }
                 count += __popcll(__ballot(alive));
             }
