@@ -25,6 +25,7 @@ EXPORTS = [
     "dr_solver_step", "dr_solver_converge", "dr_solver_reset", "dr_solver_read", "dr_solver_residual_sums",
     "dr_comm_unique_id", "dr_comm_init", "dr_get_info", "dr_profile_enable", "dr_profile_reset",
     "dr_synchronize", "dr_debug_read_bvh", "dr_shard_rows", "dr_residual_offset",
+    "dr_comm_manual", "dr_exchange_export", "dr_exchange_import",
 ]
 
 
@@ -79,6 +80,9 @@ def load_library(path=None):
     L.dr_profile_reset.argtypes = [vp]
     L.dr_synchronize.argtypes = [vp]
     L.dr_debug_read_bvh.argtypes = [vp, vp, i]
+    L.dr_comm_manual.argtypes = [vp]
+    L.dr_exchange_export.argtypes = [vp, vp]
+    L.dr_exchange_import.argtypes = [vp, i, vp]
     L.dr_shard_rows.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.dr_residual_offset.argtypes = [i, i, i, i]
     for name in EXPORTS:
@@ -172,6 +176,19 @@ class Context:
         id128 = np.ascontiguousarray(id128, dtype=np.uint8)
         assert id128.size == 128
         self._chk(self.L.dr_comm_init(self.h, _p(id128), int(rank), int(world)), "dr_comm_init")
+
+    def comm_manual(self):
+        self._chk(self.L.dr_comm_manual(self.h), "dr_comm_manual")
+
+    def exchange_export(self):
+        _, _, rpr = self.shard()
+        out = np.empty(self.S * rpr, np.float32)
+        self._chk(self.L.dr_exchange_export(self.h, _p(out)), "dr_exchange_export")
+        return out
+
+    def exchange_import(self, src_rank, chunk):
+        chunk = _f32(chunk)
+        self._chk(self.L.dr_exchange_import(self.h, int(src_rank), _p(chunk)), "dr_exchange_import")
 
     # -- scene
     def set_mesh(self, vertices, normals, tri_v, tri_n):

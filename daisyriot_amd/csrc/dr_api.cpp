@@ -72,6 +72,7 @@ struct dr_context {
     int cur = 0;
     bool have_solver = false;
     Comm comm;
+    bool manual_exchange = false;
     // measurement
     double last_assemble_ms = 0, last_bvh_ms = 0;
     unsigned long long pairs_traced = 0, stat_visits = 0, stat_leaves = 0;
@@ -414,7 +415,7 @@ int dr_solver_init(dr_context* c, int S, const float* E, const float* M, int n_m
         if (mat_of_patch[i] < 0 || mat_of_patch[i] >= n_mat)
             return fail(DR_ERR_INVALID, "material index %d of patch %d out of range [0,%d)", mat_of_patch[i], i, n_mat);
     // DR_NO_COMM=1: time one rank's shard alone (its residual chunks of other ranks stay at E)
-    if (c->world > 1 && !c->comm.comm && !getenv("DR_NO_COMM"))
+    if (c->world > 1 && !c->comm.comm && !c->manual_exchange && !getenv("DR_NO_COMM"))
         return fail(DR_ERR_STATE, "world=%d but dr_comm_init has not been called", c->world);
     HIPCHK(hipStreamSynchronize(c->stream));
     free_solver(c);
@@ -548,6 +549,33 @@ int dr_debug_read_bvh(dr_context* c, void* out, int max_nodes) {
     if (c->N <= 0) return fail(DR_ERR_STATE, "no mesh");
     if (!out || max_nodes < c->n_nodes) return fail(DR_ERR_INVALID, "need room for %d nodes", c->n_nodes);
     HIPCHK(hipMemcpyAsync(out, c->d_bvh, sizeof(BvhNode) * (size_t)c->n_nodes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DR_OK;
+}
+
+int dr_comm_manual(dr_context* c) {
+    CTX(c);
+    comm_destroy(c->comm);
+    c->manual_exchange = true;
+    return DR_OK;
+}
+
+int dr_exchange_export(dr_context* c, float* out) {
+    CTX(c);
+    if (!c->have_solver) return fail(DR_ERR_STATE, "dr_solver_init has not been called");
+    if (!out) return fail(DR_ERR_INVALID, "chunk_out is null");
+    const size_t n = (size_t)c->S * c->rpr;
+    HIPCHK(hipMemcpyAsync(out, c->d_R[c->cur] + (size_t)c->rank * n, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DR_OK;
+}
+
+int dr_exchange_import(dr_context* c, int src_rank, const float* in) {
+    CTX(c);
+    if (!c->have_solver) return fail(DR_ERR_STATE, "dr_solver_init has not been called");
+    if (!in || src_rank < 0 || src_rank >= c->world) return fail(DR_ERR_INVALID, "bad source rank %d", src_rank);
+    const size_t n = (size_t)c->S * c->rpr;
+    HIPCHK(hipMemcpyAsync(c->d_R[c->cur] + (size_t)src_rank * n, in, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return DR_OK;
 }

@@ -138,6 +138,13 @@ int dr_solver_residual_sums(dr_context* ctx, double* sums /* S */);
 /* 128-byte RCCL unique id made on rank 0 and handed to every rank by the host. */
 int dr_comm_unique_id(void* out128);
 int dr_comm_init(dr_context* ctx, const void* id128, int rank, int world);
+/* Host-staged exchange for hosts without RCCL (MPI staging, tests): after dr_comm_manual the
+ * passes run without a collective and the host moves the residual chunks itself after EVERY
+ * dr_solver_step(ctx, 1, ..): export this rank's new chunk (S*rows_per_rank floats, bin-major),
+ * import every other rank's chunk. */
+int dr_comm_manual(dr_context* ctx);
+int dr_exchange_export(dr_context* ctx, float* chunk_out);
+int dr_exchange_import(dr_context* ctx, int src_rank, const float* chunk_in);
 
 /* ---- measurement ----------------------------------------------------------------- */
 typedef struct {
