@@ -324,14 +324,26 @@ __device__ __forceinline__ bool tri_hit(f3 o, f3 d, f3 a, f3 e1, f3 e2, float& t
 // conservative slab test of the segment [0,tmax] against a (padded) box held in SGPRs.
 // t = plane*inv - org*inv as one fused multiply-add per plane (noi = -org*inv per lane): the box
 // test only has to be conservative (boxes are padded by 1e-4 of the scene), not bit-exact.
+// One compare: max(tn,0) <= min(tf*(1+eps), tmax)  <=>  tn <= tf*(1+eps), tf >= 0, tn <= tmax
+// (tmax > 0); NaNs from 0*inf are dropped by min/max.
 __device__ __forceinline__ bool box_hit(const BvhNode& nd, f3 noi, f3 inv, float tmax) {
     float t0 = __builtin_fmaf(nd.lo[0], inv.x, noi.x), t1 = __builtin_fmaf(nd.hi[0], inv.x, noi.x);
     float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
     t0 = __builtin_fmaf(nd.lo[1], inv.y, noi.y); t1 = __builtin_fmaf(nd.hi[1], inv.y, noi.y);
     tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
     t0 = __builtin_fmaf(nd.lo[2], inv.z, noi.z); t1 = __builtin_fmaf(nd.hi[2], inv.z, noi.z);
+    tn = fmaxf(fmaxf(tn, fminf(t0, t1)), 0.0f); tf = fminf(tf, fmaxf(t0, t1));
+    return tn <= fminf(tf * 1.00001f, tmax);
+}
+// the same test as a wave mask (v_cmp straight into an SGPR pair; 5 = ordered <=)
+__device__ __forceinline__ unsigned long long box_hit_mask(const BvhNode& nd, f3 noi, f3 inv, float tmax) {
+    float t0 = __builtin_fmaf(nd.lo[0], inv.x, noi.x), t1 = __builtin_fmaf(nd.hi[0], inv.x, noi.x);
+    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+    t0 = __builtin_fmaf(nd.lo[1], inv.y, noi.y); t1 = __builtin_fmaf(nd.hi[1], inv.y, noi.y);
     tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-    return (tn <= tf * 1.00001f) && (tf >= 0.0f) && (tn <= tmax);
+    t0 = __builtin_fmaf(nd.lo[2], inv.z, noi.z); t1 = __builtin_fmaf(nd.hi[2], inv.z, noi.z);
+    tn = fmaxf(fmaxf(tn, fminf(t0, t1)), 0.0f); tf = fminf(tf, fmaxf(t0, t1));
+    return __builtin_amdgcn_fcmpf(tn, fminf(tf * 1.00001f, tmax), 5);
 }
 
 __device__ __forceinline__ float safe_inv(float d) {
@@ -477,20 +489,23 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
                 // leaf could have retired lanes.  Every step moves forward in pre-order, so the node
                 // count bounds the walk even if the node array were corrupt.
                 const unsigned n_nodes = (unsigned)P.n_nodes;
-                unsigned node = (__ballot(alive) == 0ull) ? n_nodes : 0u;
+                // liveness as an explicit wave mask in SGPRs: no per-step ballot
+                unsigned long long alive_m = __builtin_amdgcn_ballot_w64(alive);
+                unsigned node = (alive_m == 0ull) ? n_nodes : 0u;
                 while (node < n_nodes) {
                     // the whole 32-byte node in one scalar load (field-wise loads would chain latencies)
                     // (float vector + __float_as_int: __builtin_bit_cast on a vector ELEMENT reads element 0)
-                    const v8f raw = *reinterpret_cast<const v8f*>(P.bvh + node);
+                    // base + 32-bit byte offset: selects the SGPR-offset form of s_load (no 64-bit address math)
+                    const v8f raw = *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(P.bvh) + node * 32u);
                     BvhNode nd;
                     nd.lo[0] = raw[0]; nd.lo[1] = raw[1]; nd.lo[2] = raw[2];
                     nd.hi[0] = raw[3]; nd.hi[1] = raw[4]; nd.hi[2] = raw[5];
                     const int nd_skip = __builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
                     const int leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
                     if (STATS) n_visit++;
-                    // no short-circuit: the slab test runs for every lane, dead ones are masked after
-                    const bool hb = box_hit(nd, noi, inv, tmax) & alive;
-                    if (__ballot(hb) == 0ull) { node = max((unsigned)nd_skip, node + 1u); continue; }
+                    // the slab test runs for every lane, dead ones are masked after
+                    const unsigned long long hb_m = box_hit_mask(nd, noi, inv, tmax) & alive_m;
+                    if (hb_m == 0ull) { node = max((unsigned)nd_skip, node + 1u); continue; }
                     node = node + 1;
                     if (leaf < 0) continue;
                     if (STATS) n_leaf++;
@@ -499,7 +514,7 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
                     // with degenerate triangles, which never hit) and tested; a record beyond the
                     // leaf's count is masked.  The destination itself needs no exclusion: its t equals
                     // tmax bit for bit and its id is not lower than its own.
-                    const v4f* tp = reinterpret_cast<const v4f*>(P.tri_sorted + first);
+                    const v4f* tp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(P.tri_sorted) + (unsigned)first * 48u);
                     v4f q[3 * LEAF_MAX];
 #pragma unroll
                     for (int c = 0; c < 3 * LEAF_MAX; c++) q[c] = tp[c];
@@ -516,10 +531,10 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
                         // closest hit is not `hi`: something nearer, or an equal-t hit of lower id
                         blocked = blocked | (h & (c < cnt) & ((tt < tmax) | ((tt == tmax) & (tk < hi))));
                     }
-                    alive = alive & !(blocked & hb);
-                    if (__ballot(alive) == 0ull) break;
+                    alive_m &= ~(__builtin_amdgcn_ballot_w64(blocked) & hb_m);
+                    if (alive_m == 0ull) break;
                 }
-                count += __popcll(__ballot(alive));
+                count += __popcll(alive_m);
             }
             if (lane == 0) sVis[i][j] = (unsigned char)count;
             if (STATS && lane == 0) {
