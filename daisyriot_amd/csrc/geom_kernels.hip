@@ -321,21 +321,12 @@ __device__ __forceinline__ bool tri_hit(f3 o, f3 d, f3 a, f3 e1, f3 e2, float& t
     return (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t > 0.0f);
 }
 
-// conservative slab test of the segment [0,tmax] against a (padded) box held in SGPRs.
-// t = plane*inv - org*inv as one fused multiply-add per plane (noi = -org*inv per lane): the box
-// test only has to be conservative (boxes are padded by 1e-4 of the scene), not bit-exact.
-// One compare: max(tn,0) <= min(tf*(1+eps), tmax)  <=>  tn <= tf*(1+eps), tf >= 0, tn <= tmax
-// (tmax > 0); NaNs from 0*inf are dropped by min/max.
-__device__ __forceinline__ bool box_hit(const BvhNode& nd, f3 noi, f3 inv, float tmax) {
-    float t0 = __builtin_fmaf(nd.lo[0], inv.x, noi.x), t1 = __builtin_fmaf(nd.hi[0], inv.x, noi.x);
-    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
-    t0 = __builtin_fmaf(nd.lo[1], inv.y, noi.y); t1 = __builtin_fmaf(nd.hi[1], inv.y, noi.y);
-    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-    t0 = __builtin_fmaf(nd.lo[2], inv.z, noi.z); t1 = __builtin_fmaf(nd.hi[2], inv.z, noi.z);
-    tn = fmaxf(fmaxf(tn, fminf(t0, t1)), 0.0f); tf = fminf(tf, fmaxf(t0, t1));
-    return tn <= fminf(tf * 1.00001f, tmax);
-}
-// the same test as a wave mask (v_cmp straight into an SGPR pair; 5 = ordered <=)
+// Conservative slab test of the segment [0,tmax] against a (padded) box held in SGPRs, as a wave
+// mask (v_cmp straight into an SGPR pair; predicate 5 = ordered <=).  t = plane*inv - org*inv is one
+// fused multiply-add per plane (noi = -org*inv per lane): the box test only has to be conservative
+// (boxes are padded by 1e-4 of the scene), not bit-exact.  One compare:
+// max(tn,0) <= min(tf*(1+eps), tmax)  <=>  tn <= tf*(1+eps), tf >= 0, tn <= tmax  (tmax > 0);
+// NaNs from 0*inf are dropped by min/max.
 __device__ __forceinline__ unsigned long long box_hit_mask(const BvhNode& nd, f3 noi, f3 inv, float tmax) {
     float t0 = __builtin_fmaf(nd.lo[0], inv.x, noi.x), t1 = __builtin_fmaf(nd.hi[0], inv.x, noi.x);
     float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
@@ -483,11 +474,11 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
                 }
                 const f3 inv = f3{ safe_inv(dn.x), safe_inv(dn.y), safe_inv(dn.z) };
                 const f3 noi = f3{ -(org.x * inv.x), -(org.y * inv.y), -(org.z * inv.z) };
-                // Walk the threaded BVH with a wave-uniform node index.  The loop is scalar-unit
-                // heavy (branches, masks, address arithmetic), so it is kept minimal: one node load,
-                // one slab test, one ballot per step; the "any lane still alive" test only runs after a
-                // leaf could have retired lanes.  Every step moves forward in pre-order, so the node
-                // count bounds the walk even if the node array were corrupt.
+                // Walk the threaded BVH with a wave-uniform node index.  The scalar unit (one per CU)
+                // carries as many instructions as the vector units here, so the step is kept minimal:
+                // one scalar node load at an SGPR offset, one slab test ending in a single v_cmp, one
+                // s_and with the liveness mask; the "any lane still alive" test only runs after a leaf
+                // could have retired lanes.  Every step moves forward in pre-order, so the walk ends.
                 const unsigned n_nodes = (unsigned)P.n_nodes;
                 // liveness as an explicit wave mask in SGPRs: no per-step ballot
                 unsigned long long alive_m = __builtin_amdgcn_ballot_w64(alive);

@@ -361,3 +361,55 @@ def test_row_sharded_solver_on_one_gpu(world, uv50):
         assert np.allclose(Rc, R1, rtol=2e-6, atol=1e-12)
         c.close()
     assert np.allclose(B, B1, rtol=2e-6, atol=1e-12)
+
+
+def test_context_reuse_and_limits(uv50):
+    """one context through several scenes / rules / bin counts; argument limits"""
+    with api.Context(0) as c:
+        for n, S in ((130, 3), (64, 8), (257, 1)):
+            sc = scenes.cornell_box(n, S=S)
+            m = _mesh(sc)
+            c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+            for rule in (api.RULE_RECIPROCITY, api.RULE_INTEGRAND):
+                c.assemble(uv50, rule=rule, keep_visibility=(rule == api.RULE_INTEGRAND))
+                Fo, _, _ = ob.assemble_rows(m, uv50, rule=rule, bvh=True, want_vis=False)
+                assert np.array_equal(_bits(c.read_rows(0, sc.N)), _bits(Fo))
+            E = sc.emission(3.0)
+            for _ in range(2):
+                c.solver_init(E, sc.M, sc.mat_of_patch)
+                c.step(2)
+            B, R = c.read()
+            Ro, Bo = E.copy(), E.copy()
+            for _ in range(2):
+                Ro = ob.sweep_rows(Fo, sc.M, sc.mat_of_patch, Ro, Bo)
+            assert np.allclose(B, Bo, rtol=2e-5, atol=1e-9)
+            with pytest.raises(api.DaisyRiotError):
+                c.read_rows(sc.N - 1, 2)                           # past the last row
+            with pytest.raises(api.DaisyRiotError):
+                c.solver_init(E, sc.M, np.full(sc.N, 99, np.int32))  # material index out of range
+        # K limits: counts are bytes with 255 as the "not traced" mark
+        sc = scenes.facing_squares(cells=1, S=1)
+        c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+        uv = scenes.visibility_samples(254, seed=9)
+        c.assemble(uv, keep_visibility=True)
+        vis = c.read_visibility(0, sc.N)
+        _, viso, _ = ob.assemble_rows(_mesh(sc), uv, bvh=False)
+        assert np.array_equal(vis, viso) and vis[vis != 255].max() == 254
+        with pytest.raises(api.DaisyRiotError):
+            c.assemble(scenes.visibility_samples(255))
+        bad = sc.vertices.copy()
+        bad[0, 0] = np.nan
+        with pytest.raises(api.DaisyRiotError):
+            c.set_mesh(bad, sc.normals, sc.tri_v, sc.tri_n)
+        with pytest.raises(api.DaisyRiotError):
+            c.set_mesh(np.zeros((0, 3), np.float32), sc.normals, np.zeros((0, 3), np.int32), np.zeros((0, 3), np.int32))
+    # two triangles only
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [0, 1, 1]], np.float32)
+    nn = np.array([[0, 0, 1], [0, 0, -1]], np.float32)
+    tv, tn = np.array([[0, 1, 2], [3, 5, 4]], np.int32), np.array([[0, 0, 0], [1, 1, 1]], np.int32)
+    with api.Context(0) as c:
+        c.set_mesh(v, nn, tv, tn)
+        c.assemble(uv50, keep_visibility=True)
+        F, vis = c.read_rows(0, 2), c.read_visibility(0, 2)
+    Fo, viso, _ = ob.assemble_rows(ob.Mesh(v, nn, tv, tn), uv50, bvh=False)
+    assert np.array_equal(_bits(F), _bits(Fo)) and np.array_equal(vis, viso) and F[0, 1] > 0
