@@ -322,17 +322,18 @@ __device__ __forceinline__ bool tri_hit(f3 o, f3 d, f3 a, f3 e1, f3 e2, float& t
 }
 
 // Conservative slab test of the segment [0,tmax] against a (padded) box held in SGPRs, as a wave
-// mask (v_cmp straight into an SGPR pair; predicate 5 = ordered <=).  t = plane*inv - org*inv is one
-// fused multiply-add per plane (noi = -org*inv per lane): the box test only has to be conservative
-// (boxes are padded by 1e-4 of the scene), not bit-exact.  One compare:
-// max(tn,0) <= min(tf*(1+eps), tmax)  <=>  tn <= tf*(1+eps), tf >= 0, tn <= tmax  (tmax > 0);
-// NaNs from 0*inf are dropped by min/max.
-__device__ __forceinline__ unsigned long long box_hit_mask(const BvhNode& nd, f3 noi, f3 inv, float tmax) {
-    float t0 = __builtin_fmaf(nd.lo[0], inv.x, noi.x), t1 = __builtin_fmaf(nd.hi[0], inv.x, noi.x);
+// mask (v_cmp straight into an SGPR pair; predicate 5 = ordered <=).  t = (plane - org) * inv: the
+// subtraction first -- the cheaper plane*inv - org*inv (one fma per plane) cancels catastrophically for
+// rays nearly parallel to a slab (|org*inv| ~ 1e7 loses the whole t range) and then culls true
+// blockers; seen on the reference's colorballs scene, whose walls are slightly tilted.
+// One compare: max(tn,0) <= min(tf*(1+eps), tmax)  <=>  tn <= tf*(1+eps), tf >= 0, tn <= tmax
+// (tmax > 0); NaNs from 0*inf are dropped by min/max.
+__device__ __forceinline__ unsigned long long box_hit_mask(const BvhNode& nd, f3 org, f3 inv, float tmax) {
+    float t0 = (nd.lo[0] - org.x) * inv.x, t1 = (nd.hi[0] - org.x) * inv.x;
     float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
-    t0 = __builtin_fmaf(nd.lo[1], inv.y, noi.y); t1 = __builtin_fmaf(nd.hi[1], inv.y, noi.y);
+    t0 = (nd.lo[1] - org.y) * inv.y; t1 = (nd.hi[1] - org.y) * inv.y;
     tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-    t0 = __builtin_fmaf(nd.lo[2], inv.z, noi.z); t1 = __builtin_fmaf(nd.hi[2], inv.z, noi.z);
+    t0 = (nd.lo[2] - org.z) * inv.z; t1 = (nd.hi[2] - org.z) * inv.z;
     tn = fmaxf(fmaxf(tn, fminf(t0, t1)), 0.0f); tf = fminf(tf, fmaxf(t0, t1));
     return __builtin_amdgcn_fcmpf(tn, fminf(tf * 1.00001f, tmax), 5);
 }
@@ -473,7 +474,6 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
                     alive = tri_hit(org, dn, ha, he1, he2, tmax);   // the destination must be hit at all
                 }
                 const f3 inv = f3{ safe_inv(dn.x), safe_inv(dn.y), safe_inv(dn.z) };
-                const f3 noi = f3{ -(org.x * inv.x), -(org.y * inv.y), -(org.z * inv.z) };
                 // Walk the threaded BVH with a wave-uniform node index.  The scalar unit (one per CU)
                 // carries as many instructions as the vector units here, so the step is kept minimal:
                 // one scalar node load at an SGPR offset, one slab test ending in a single v_cmp, one
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
                     const int leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
                     if (STATS) n_visit++;
                     // the slab test runs for every lane, dead ones are masked after
-                    const unsigned long long hb_m = box_hit_mask(nd, noi, inv, tmax) & alive_m;
+                    const unsigned long long hb_m = box_hit_mask(nd, org, inv, tmax) & alive_m;
                     if (hb_m == 0ull) { node = max((unsigned)nd_skip, node + 1u); continue; }
                     node = node + 1;
                     if (leaf < 0) continue;

@@ -67,3 +67,33 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def reference_scenes():
+    """The reference's two example scenes (data files under /root/reference/example_scenes) parsed by
+    the C++ host loader and stored as arrays, so that BASELINE.json's configs 0 and 1 can be run
+    where the reference tree is absent (the GPU box)."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_host_loader_cpu as hl
+    C.CDLL(os.path.join(ROOT, "daisyriot_amd", "lib", "libdaisyriot_hip.so"), mode=C.RTLD_GLOBAL)
+    L = C.CDLL(hl.HOST)
+    L.drh_mesh_load.restype = C.c_void_p
+    L.drh_mesh_load.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int]
+    L.drh_mesh_free.argtypes = [C.c_void_p]
+    L.drh_mesh_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+    L.drh_mesh_warnings.restype = C.c_char_p
+    L.drh_mesh_warnings.argtypes = [C.c_void_p]
+    L.drh_mesh_copy.argtypes = [C.c_void_p] * 6
+    L.drh_mesh_materials.argtypes = [C.c_void_p] * 7
+    L.drh_vertex_fanout.argtypes = [C.c_void_p, C.c_int]
+    for name in ("cornellbox_blacklight", "colorballs"):
+        got = hl.load(L, "/root/reference/example_scenes/%s.obj" % name, "/root/reference/example_scenes/", hl.WL9)
+        np.savez_compressed(os.path.join(OUT, "scene_%s.npz" % name), vertices=got["vertices"], normals=got["normals"],
+                            tri_v=got["tri_v"], tri_n=got["tri_n"], mat=got["mat"], kind=got["kind"],
+                            Kd=got["rgb"], Ke=got["emission"])
+        print(name, got["tri_v"].shape[0], "triangles")
+
+
+if __name__ == "__main__" and os.path.isdir("/root/reference/example_scenes"):
+    reference_scenes()

@@ -413,3 +413,36 @@ def test_context_reuse_and_limits(uv50):
         F, vis = c.read_rows(0, 2), c.read_visibility(0, 2)
     Fo, viso, _ = ob.assemble_rows(ob.Mesh(v, nn, tv, tn), uv50, bvh=False)
     assert np.array_equal(_bits(F), _bits(Fo)) and np.array_equal(vis, viso) and F[0, 1] > 0
+
+
+def _bowl_scene():
+    """two facing sheets; the lower one is a very shallow bowl with per-triangle geometric normals, so
+    its own patches face each other at grazing angles; everything sits far from the origin"""
+    sc = scenes.facing_squares(cells=6, gap=1.0, S=1)
+    v = sc.vertices.astype(np.float64)
+    lower = np.isclose(v[:, 1], 0.0)
+    v[lower, 1] += 0.01 * ((v[lower, 0] - 0.5) ** 2 + (v[lower, 2] - 0.5) ** 2)
+    v += 3.7
+    v = v.astype(np.float32)
+    a, b, c = (v[sc.tri_v[:, k]].astype(np.float64) for k in range(3))
+    n = np.cross(b - a, c - a)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    tn = np.repeat(np.arange(sc.N, dtype=np.int32)[:, None], 3, axis=1)
+    return v, n.astype(np.float32), sc.tri_v, tn, sc.N
+
+
+def test_grazing_rays_along_a_shallow_bowl(uv50):
+    """nearly coplanar patches that do face each other (as on the slightly tilted walls of the
+    reference's colorballs scene): rays run almost parallel to thin BVH boxes far from the origin --
+    the slab test must stay conservative (an fma-folded slab test loses the whole t range here)"""
+    v, nrm, tv, tn, N = _bowl_scene()
+    with api.Context(0) as c:
+        c.set_mesh(v, nrm, tv, tn)
+        c.assemble(uv50, keep_visibility=True)
+        vis, F = c.read_visibility(0, N), c.read_rows(0, N)
+    Fo, viso, _ = ob.assemble_rows(ob.Mesh(v, nrm, tv, tn), uv50, bvh=False)
+    n1 = N // 2
+    sub = viso[:n1, :n1]
+    assert (sub != 255).sum() > 100 and (sub[sub != 255] < 50).any()   # in-sheet pairs are traced, some blocked
+    assert np.array_equal(vis, viso)
+    assert np.array_equal(_bits(F), _bits(Fo))

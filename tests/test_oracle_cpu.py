@@ -191,3 +191,16 @@ def test_sample_set_and_scenes():
     f = sc.material_names.index("fluorescent")
     assert np.allclose(np.diag(sc.M[f])[[0, 1, 2, 4]], 1.0)          # unit diagonal outside the UV bins
     assert sc.emit[sc.material_names.index("uvlamp")].argmax() == 3   # 350 nm
+
+
+@pytest.mark.parametrize("name,nnz,rs_mean,rs_max", [("cornellbox_blacklight", 0.193, 0.863, 1.52),
+                                                    ("colorballs", 0.294, 0.691, 1.09)])
+def test_integrand_statistics_of_the_reference_run(name, nnz, rs_mean, rs_max):
+    """the reference's unmodified triangle_math.cpp, driven over the first 256
+    rows of its own example scenes, gave these nonzero fractions and row sums; the oracle must too."""
+    g = np.load(os.path.join(GOLD, "scene_%s.npz" % name))
+    m = ob.Mesh(g["vertices"], g["normals"], g["tri_v"], g["tri_n"])
+    Fu = ob.integrand_rows(m, 0, 256)
+    rs = Fu.sum(axis=1, dtype=np.float64)
+    assert abs((Fu > 0).mean() - nnz) < 0.0005
+    assert abs(rs.mean() - rs_mean) < 0.0005 and abs(rs.max() - rs_max) < 0.005
