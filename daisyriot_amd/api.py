@@ -25,7 +25,7 @@ EXPORTS = [
     "dr_solver_step", "dr_solver_converge", "dr_solver_reset", "dr_solver_read", "dr_solver_residual_sums",
     "dr_comm_unique_id", "dr_comm_init", "dr_get_info", "dr_profile_enable", "dr_profile_reset",
     "dr_synchronize", "dr_debug_read_bvh", "dr_shard_rows", "dr_residual_offset",
-    "dr_comm_manual", "dr_exchange_export", "dr_exchange_import",
+    "dr_comm_manual", "dr_exchange_export", "dr_exchange_import", "dr_debug_read_array",
 ]
 
 
@@ -80,6 +80,7 @@ def load_library(path=None):
     L.dr_profile_reset.argtypes = [vp]
     L.dr_synchronize.argtypes = [vp]
     L.dr_debug_read_bvh.argtypes = [vp, vp, i]
+    L.dr_debug_read_array.argtypes = [vp, i, vp, C.c_size_t]
     L.dr_comm_manual.argtypes = [vp]
     L.dr_exchange_export.argtypes = [vp, vp]
     L.dr_exchange_import.argtypes = [vp, i, vp]
@@ -282,6 +283,11 @@ class Context:
         dt = np.dtype([("lo", np.float32, 3), ("hi", np.float32, 3), ("skip", np.int32), ("tri", np.int32)])
         out = np.zeros(n, dt)
         self._chk(self.L.dr_debug_read_bvh(self.h, _p(out), n), "dr_debug_read_bvh")
+        return out
+
+    def read_array(self, which, nbytes):
+        out = np.zeros(nbytes, np.uint8)
+        self._chk(self.L.dr_debug_read_array(self.h, int(which), _p(out), nbytes), "dr_debug_read_array")
         return out
 
     def synchronize(self):

@@ -198,7 +198,7 @@ int dr_context_create(int device_id, dr_context** out) {
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(DR_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
-    e = hipMalloc(&c->d_counter, 4 * sizeof(unsigned long long));
+    e = hipMalloc(&c->d_counter, 16 * sizeof(unsigned long long));
     if (e != hipSuccess) { hipStreamDestroy(c->own_stream); delete c; return fail(DR_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
     *out = c;
     return DR_OK;
@@ -286,7 +286,9 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     HIPCHK(hipMemcpyAsync(c->d_nrm, normals, sizeof(float) * 3 * (size_t)Nn, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_tv, tv, sizeof(int) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_tn, tn, sizeof(int) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(launch_patch_records(c->stream, N, c->d_vtx, c->d_nrm, c->d_tv, c->d_tn, c->d_patch, c->d_tri));
+    // padding of every triangle's gate box: 1e-4 of the largest side of the scene (fp32, as the oracle)
+    const float box_pad = 1e-4f * std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2])) + 1e-30f;
+    HIPCHK(launch_patch_records(c->stream, N, c->d_vtx, c->d_nrm, c->d_tv, c->d_tn, box_pad, c->d_patch, c->d_tri));
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -319,7 +321,7 @@ static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int r
         HIPCHK(hipMalloc(&c->d_uv, sizeof(float) * 2 * (size_t)K));
         HIPCHK(hipMemcpyAsync(c->d_uv, uv, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(hipMemsetAsync(c->d_counter, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_counter, 0, 16 * sizeof(unsigned long long), c->stream));
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -332,17 +334,22 @@ static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int r
         p.F = c->d_F; p.vis = c->d_vis; p.patch = c->d_patch; p.tri = c->d_tri; p.tri_sorted = c->d_tri_sorted; p.bvh = c->d_bvh;
         p.uv = c->d_uv; p.pairs_traced = c->d_counter;
         p.stats = getenv("DR_TILE_STATS") ? 1 : 0;
+        p.dbg_lo = p.dbg_hi = -1;
+        if (const char* dp = getenv("DR_DEBUG_PAIR")) { p.stats = 1; p.dbg_ray = 0; sscanf(dp, "%d,%d,%d", &p.dbg_lo, &p.dbg_hi, &p.dbg_ray); }
         HIPCHK(launch_ff_tiles(c->stream, p));
     }
     HIPCHK(hipEventRecord(e1, c->stream));
-    unsigned long long cnt[4] = { 0, 0, 0, 0 };
+    unsigned long long cnt[16] = { 0 };
     HIPCHK(hipMemcpyAsync(cnt, c->d_counter, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     c->last_assemble_ms = ms;
     c->pairs_traced = cnt[0]; c->stat_visits = cnt[1]; c->stat_leaves = cnt[2];
-    if (getenv("DR_TILE_STATS"))
+    if (getenv("DR_DEBUG_PAIR"))
+        fprintf(stderr, "[daisyriot] debug pair: live mask after target test %016llx, final %016llx; blocker of the debug ray: patch %lld "
+                        "t %08llx tmax %08llx node %llu\n", cnt[1], cnt[3], (long long)cnt[4], cnt[5], cnt[6], cnt[7]);
+    else if (getenv("DR_TILE_STATS"))
         fprintf(stderr, "[daisyriot] pairs %llu, node visits %llu (%.1f/pair), leaf tests %llu (%.1f/pair)\n", cnt[0], cnt[1],
                 cnt[0] ? (double)cnt[1] / cnt[0] : 0.0, cnt[2], cnt[0] ? (double)cnt[2] / cnt[0] : 0.0);
     hipEventDestroy(e0); hipEventDestroy(e1);
@@ -576,6 +583,23 @@ int dr_exchange_import(dr_context* c, int src_rank, const float* in) {
     if (!in || src_rank < 0 || src_rank >= c->world) return fail(DR_ERR_INVALID, "bad source rank %d", src_rank);
     const size_t n = (size_t)c->S * c->rpr;
     HIPCHK(hipMemcpyAsync(c->d_R[c->cur] + (size_t)src_rank * n, in, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DR_OK;
+}
+
+int dr_debug_read_array(dr_context* c, int which, void* out, size_t bytes) {
+    CTX(c);
+    const void* src = nullptr;
+    size_t have = 0;
+    switch (which) {
+        case 0: src = c->d_tri; have = sizeof(TriRec) * (size_t)c->N; break;
+        case 1: src = c->d_tri_sorted; have = sizeof(TriRec) * ((size_t)c->N + LEAF_MAX); break;
+        case 3: src = c->d_uv; have = bytes; break;
+        case 4: src = c->d_patch; have = sizeof(PatchRec) * (size_t)c->N; break;
+        default: return fail(DR_ERR_INVALID, "unknown array %d", which);
+    }
+    if (!src || !out || bytes > have) return fail(DR_ERR_INVALID, "array %d: %zu bytes asked, %zu available", which, bytes, have);
+    HIPCHK(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return DR_OK;
 }

@@ -16,12 +16,16 @@ struct PatchRec {
     float area;        // patch area
 };                      // 20 floats
 
-// a, e1 = b-a, e2 = c-a : uv2xyz (vs/triangle_math.cpp:3-9) and the ray/triangle test
+// a, e1 = b-a, e2 = c-a : uv2xyz (vs/triangle_math.cpp:3-9) and the ray/triangle test;
+// lo/hi: bounding box of (a, a+e1, a+e2) padded by 1e-4 of the scene extent -- a triangle can only be
+// hit by a segment that passes this box (the gate that makes fp32 "hits" geometric, see oracle.c)
 struct TriRec {
     float a[3], e1[3], e2[3];
-    int   id;           // original patch index (the leaf array is in Morton order)
-    float pad[2];
-};                      // 12 dwords = 48 B
+    int   id;           // original patch index (the leaf arrays are in Morton order)
+    float lo[3], hi[3];
+};                      // 16 dwords = 64 B
+
+
 
 // Threaded BVH node in depth-first pre-order: the first child of an internal node is
 // node+1; `skip` is the pre-order index of the first node after this node's subtree.
@@ -31,7 +35,8 @@ struct BvhNode {
     int   tri;          // leaf: first*8 + (count-1) into the Morton-ordered TriRec array; -1: internal
 };                      // 32 B: one s_load_dwordx8
 
-constexpr int LEAF_MAX = 4;     // subtrees of up to this many triangles are collapsed into one leaf
+constexpr int LEAF_MAX = 2;     // subtrees of up to this many triangles are collapsed into one leaf
+                                // (a leaf is fetched whole: LEAF_MAX x 16 SGPRs)
 
 constexpr int TILE = 64;        // patch-pair tile edge of the assembly kernel
 constexpr int SHARD_ALIGN = 256; // rows per rank are a multiple of this (sweep column tile)
@@ -44,11 +49,13 @@ struct TileParams {
     unsigned char* vis;       // nullable, vis[(row-row0)*N + col]
     const PatchRec* patch;
     const TriRec* tri;          // original order (ray generation)
-    const TriRec* tri_sorted;   // Morton order, LEAF_MAX padding records at the end (leaf tests)
+    const TriRec* tri_sorted;   // Morton order, LEAF_MAX never-hit padding records at the end (leaf tests)
     const BvhNode* bvh;
     const float* uv;          // K x 2
     unsigned long long* pairs_traced;   // [0] pairs traced, [1] BVH nodes visited, [2] leaves tested (wave level)
     int stats;                          // count [1],[2] too (debug; costs two atomics per pair)
+    int dbg_ray;
+    int dbg_lo, dbg_hi;                 // STATS build: [3] = final live-ray mask of this pair, [1] = mask after the target test
 };
 
 struct SweepParams {
@@ -73,7 +80,7 @@ struct SweepParams {
 
 // launchers implemented in the .hip files
 hipError_t launch_patch_records(hipStream_t st, int N, const float* vtx, const float* nrm,
-                                const int* tv, const int* tn, PatchRec* patch, TriRec* tri);
+                                const int* tv, const int* tn, float box_pad, PatchRec* patch, TriRec* tri);
 hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float scene_lo[3],
                       const float scene_hi[3], BvhNode* nodes /* room for 2N-1 */,
                       TriRec* tri_sorted /* N + LEAF_MAX */, int* n_nodes_out);

@@ -51,7 +51,7 @@ __device__ __forceinline__ f3 centre3(f3 p0, f3 p1, f3 p2) {
 // per-patch records
 // ---------------------------------------------------------------------------------------
 __global__ void k_patch_records(int N, const float* __restrict__ vtx, const float* __restrict__ nrm,
-                                const int* __restrict__ tv, const int* __restrict__ tn,
+                                const int* __restrict__ tv, const int* __restrict__ tn, float box_pad,
                                 PatchRec* __restrict__ patch, TriRec* __restrict__ tri) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= N) return;
@@ -84,13 +84,19 @@ __global__ void k_patch_records(int N, const float* __restrict__ vtx, const floa
     T.a[0] = a.x; T.a[1] = a.y; T.a[2] = a.z;
     T.e1[0] = e1.x; T.e1[1] = e1.y; T.e1[2] = e1.z;
     T.e2[0] = e2.x; T.e2[1] = e2.y; T.e2[2] = e2.z;
-    T.id = t; T.pad[0] = 0.0f; T.pad[1] = 0.0f;
+    T.id = t;
+    const float px[3][3] = { { a.x, a.y, a.z }, { a.x + e1.x, a.y + e1.y, a.z + e1.z }, { a.x + e2.x, a.y + e2.y, a.z + e2.z } };
+#pragma unroll
+    for (int x = 0; x < 3; x++) {   // the box of the triangle the ray test sees, padded (same floats as the oracle)
+        T.lo[x] = fminf(px[0][x], fminf(px[1][x], px[2][x])) - box_pad;
+        T.hi[x] = fmaxf(px[0][x], fmaxf(px[1][x], px[2][x])) + box_pad;
+    }
     tri[t] = T;
 }
 
 hipError_t launch_patch_records(hipStream_t st, int N, const float* vtx, const float* nrm,
-                                const int* tv, const int* tn, PatchRec* patch, TriRec* tri) {
-    hipLaunchKernelGGL(k_patch_records, dim3((N + 255) / 256), dim3(256), 0, st, N, vtx, nrm, tv, tn, patch, tri);
+                                const int* tv, const int* tn, float box_pad, PatchRec* patch, TriRec* tri) {
+    hipLaunchKernelGGL(k_patch_records, dim3((N + 255) / 256), dim3(256), 0, st, N, vtx, nrm, tv, tn, box_pad, patch, tri);
     return hipGetLastError();
 }
 
@@ -110,12 +116,7 @@ __device__ __forceinline__ unsigned long long expand21(unsigned int v) {
 
 __device__ __forceinline__ void tri_bounds(const TriRec& T, float lo[3], float hi[3]) {
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-        float pa = T.a[a], pb = T.a[a] + T.e1[a], pc = T.a[a] + T.e2[a];
-        // (a, a+e1, a+e2) is the triangle the ray test sees; the boxes are padded on top
-        lo[a] = fminf(pa, fminf(pb, pc));
-        hi[a] = fmaxf(pa, fmaxf(pb, pc));
-    }
+    for (int a = 0; a < 3; a++) { lo[a] = T.lo[a]; hi[a] = T.hi[a]; }
 }
 
 __global__ void k_morton(int N, const TriRec* __restrict__ tri, float3 slo, float3 sinv,
@@ -177,7 +178,7 @@ __global__ void k_refit(int N, const TriRec* __restrict__ tri, const int* __rest
                         const int* __restrict__ first, const int* __restrict__ last,
                         const int* __restrict__ parent, int* __restrict__ flags,
                         float* __restrict__ box /* (2N-1) x 6 */, int* __restrict__ esize /* 2N-1 */,
-                        TriRec* __restrict__ tri_sorted, float pad) {
+                        TriRec* __restrict__ tri_sorted) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
     const TriRec T = tri[sorted_tri[k]];
@@ -186,7 +187,9 @@ __global__ void k_refit(int N, const TriRec* __restrict__ tri, const int* __rest
     tri_bounds(T, lo, hi);
     int id = N - 1 + k;
     float* b = box + 6 * (size_t)id;
-    for (int a = 0; a < 3; a++) { lo[a] -= pad; hi[a] += pad; b[a] = lo[a]; b[3 + a] = hi[a]; }
+    // node boxes are plain unions of the triangles' (already padded) boxes: the fp32 slab test is
+    // monotone under box enlargement, so culling by them is exact
+    for (int a = 0; a < 3; a++) { b[a] = lo[a]; b[3 + a] = hi[a]; }
     esize[id] = 1;
     int es = 1;                                 // nodes this subtree contributes to the output
     int p = (N > 1) ? parent[id] : -1;
@@ -239,10 +242,10 @@ __global__ void k_emit(int N, const int* __restrict__ left, const int* __restric
 
 __global__ void k_pad_tris(int N, TriRec* __restrict__ tri_sorted) {
     int k = threadIdx.x;
-    if (k < LEAF_MAX) {                 // records a leaf's fixed-width fetch may touch past the end
-        TriRec T;
-        for (int a = 0; a < 3; a++) { T.a[a] = 0.0f; T.e1[a] = 0.0f; T.e2[a] = 0.0f; }
-        T.id = -1; T.pad[0] = T.pad[1] = 0.0f;
+    if (k < LEAF_MAX) {                 // records a leaf's fixed-width fetch may touch past the end: never hit
+        TriRec T;                       // gate = a point at +inf: every slab interval is [inf,inf] or [-inf,-inf]
+        for (int a = 0; a < 3; a++) { T.a[a] = 0.0f; T.e1[a] = 0.0f; T.e2[a] = 0.0f; T.lo[a] = INFINITY; T.hi[a] = INFINITY; }
+        T.id = -1;
         tri_sorted[N + k] = T;
     }
 }
@@ -256,8 +259,6 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
     void* tmp = nullptr;
     size_t tmp_bytes = 0;
     const size_t nn = 2 * (size_t)N - 1;
-    float ext = fmaxf(shi[0] - slo[0], fmaxf(shi[1] - slo[1], shi[2] - slo[2]));
-    float pad = 1e-4f * ext + 1e-30f;
     float3 lo3 = make_float3(slo[0], slo[1], slo[2]);
     float3 inv3 = make_float3(shi[0] > slo[0] ? 1.0f / (shi[0] - slo[0]) : 0.0f,
                               shi[1] > slo[1] ? 1.0f / (shi[1] - slo[1]) : 0.0f,
@@ -286,7 +287,7 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
             DR_TRY(hipGetLastError());
         }
         hipLaunchKernelGGL(k_refit, dim3(nb), dim3(256), 0, st, N, tri, vals2, left, right, first, last, parent, flags,
-                           box, esize, tri_sorted, pad);
+                           box, esize, tri_sorted);
         DR_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_pad_tris, dim3(1), dim3(64), 0, st, N, tri_sorted);
         DR_TRY(hipGetLastError());
@@ -328,12 +329,15 @@ __device__ __forceinline__ bool tri_hit(f3 o, f3 d, f3 a, f3 e1, f3 e2, float& t
 // blockers; seen on the reference's colorballs scene, whose walls are slightly tilted.
 // One compare: max(tn,0) <= min(tf*(1+eps), tmax)  <=>  tn <= tf*(1+eps), tf >= 0, tn <= tmax
 // (tmax > 0); NaNs from 0*inf are dropped by min/max.
-__device__ __forceinline__ unsigned long long box_hit_mask(const BvhNode& nd, f3 org, f3 inv, float tmax) {
-    float t0 = (nd.lo[0] - org.x) * inv.x, t1 = (nd.hi[0] - org.x) * inv.x;
+// Bit-identical to the oracle's slab_hit (same operations, same order): the per-triangle gate is
+// part of the definition of a hit, and the same test on enclosing boxes can then never cull a
+// triangle whose gate passes.
+__device__ __forceinline__ unsigned long long box_hit_mask(const float lo[3], const float hi[3], f3 org, f3 inv, float tmax) {
+    float t0 = (lo[0] - org.x) * inv.x, t1 = (hi[0] - org.x) * inv.x;
     float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
-    t0 = (nd.lo[1] - org.y) * inv.y; t1 = (nd.hi[1] - org.y) * inv.y;
+    t0 = (lo[1] - org.y) * inv.y; t1 = (hi[1] - org.y) * inv.y;
     tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-    t0 = (nd.lo[2] - org.z) * inv.z; t1 = (nd.hi[2] - org.z) * inv.z;
+    t0 = (lo[2] - org.z) * inv.z; t1 = (hi[2] - org.z) * inv.z;
     tn = fmaxf(fmaxf(tn, fminf(t0, t1)), 0.0f); tf = fminf(tf, fmaxf(t0, t1));
     return __builtin_amdgcn_fcmpf(tn, fminf(tf * 1.00001f, tmax), 5);
 }
@@ -471,9 +475,11 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
                     f3 dv = dst - src;
                     dn = dv * (1.0f / sqrtf(dot3(dv, dv)));
                     org = src + dn * P.eps;
-                    alive = tri_hit(org, dn, ha, he1, he2, tmax);   // the destination must be hit at all
                 }
                 const f3 inv = f3{ safe_inv(dn.x), safe_inv(dn.y), safe_inv(dn.z) };
+                // the destination must be hit at all: its gate on [0,inf) and the triangle test
+                if (alive) alive = tri_hit(org, dn, ha, he1, he2, tmax);
+                alive = alive && ((box_hit_mask(Th.lo, Th.hi, org, inv, INFINITY) >> lane) & 1ull);
                 // Walk the threaded BVH with a wave-uniform node index.  The scalar unit (one per CU)
                 // carries as many instructions as the vector units here, so the step is kept minimal:
                 // one scalar node load at an SGPR offset, one slab test ending in a single v_cmp, one
@@ -482,6 +488,7 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
                 const unsigned n_nodes = (unsigned)P.n_nodes;
                 // liveness as an explicit wave mask in SGPRs: no per-step ballot
                 unsigned long long alive_m = __builtin_amdgcn_ballot_w64(alive);
+                if (STATS && lo == P.dbg_lo && hi == P.dbg_hi && lane == 0) P.pairs_traced[1] = alive_m;
                 unsigned node = (alive_m == 0ull) ? n_nodes : 0u;
                 while (node < n_nodes) {
                     // the whole 32-byte node in one scalar load (field-wise loads would chain latencies)
@@ -495,40 +502,51 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
                     const int leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
                     if (STATS) n_visit++;
                     // the slab test runs for every lane, dead ones are masked after
-                    const unsigned long long hb_m = box_hit_mask(nd, org, inv, tmax) & alive_m;
+                    const unsigned long long hb_m = box_hit_mask(nd.lo, nd.hi, org, inv, tmax) & alive_m;
                     if (hb_m == 0ull) { node = max((unsigned)nd_skip, node + 1u); continue; }
                     node = node + 1;
                     if (leaf < 0) continue;
                     if (STATS) n_leaf++;
                     const int first = leaf >> 3, cnt = (leaf & 7) + 1;
-                    // Branch-free leaf: all LEAF_MAX records are fetched together (the array is padded
-                    // with degenerate triangles, which never hit) and tested; a record beyond the
-                    // leaf's count is masked.  The destination itself needs no exclusion: its t equals
-                    // tmax bit for bit and its id is not lower than its own.
-                    const v4f* tp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(P.tri_sorted) + (unsigned)first * 48u);
-                    v4f q[3 * LEAF_MAX];
+                    // Leaf: its LEAF_MAX records (64 B each: triangle, id, gate box) are fetched together --
+                    // no dependent loads inside the leaf; a triangle's Moller-Trumbore test only runs when some
+                    // live lane passes its gate.  The destination itself needs no exclusion: its t equals tmax
+                    // bit for bit and its id is not lower than its own.
+                    const v4f* tp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(P.tri_sorted) + (unsigned)first * 64u);
+                    v4f q[4 * LEAF_MAX];
 #pragma unroll
-                    for (int c = 0; c < 3 * LEAF_MAX; c++) q[c] = tp[c];
-                    bool blocked = false;
+                    for (int c = 0; c < 4 * LEAF_MAX; c++) q[c] = tp[c];
+                    unsigned long long blocked_m = 0ull;
 #pragma unroll
                     for (int c = 0; c < LEAF_MAX; c++) {
-                        const v4f A = q[3 * c], B = q[3 * c + 1], C3 = q[3 * c + 2];
+                        const v4f A = q[4 * c], B = q[4 * c + 1], C3 = q[4 * c + 2], D = q[4 * c + 3];
+                        const float blo[3] = { C3[2], C3[3], D[0] }, bhi[3] = { D[1], D[2], D[3] };
+                        const unsigned long long gm = box_hit_mask(blo, bhi, org, inv, tmax) & alive_m;
+                        if (gm == 0ull || c >= cnt) continue;      // (slots past the leaf's count belong to the next leaf)
+                        const int tk = __builtin_amdgcn_readfirstlane(__float_as_int(C3[1]));
                         const f3 ta = f3{ A[0], A[1], A[2] };
                         const f3 te1 = f3{ A[3], B[0], B[1] };
                         const f3 te2 = f3{ B[2], B[3], C3[0] };
-                        const int tk = __builtin_amdgcn_readfirstlane(__float_as_int(C3[1]));
                         float tt;
                         const bool h = tri_hit(org, dn, ta, te1, te2, tt);
                         // closest hit is not `hi`: something nearer, or an equal-t hit of lower id
-                        blocked = blocked | (h & (c < cnt) & ((tt < tmax) | ((tt == tmax) & (tk < hi))));
+                        const unsigned long long bm = gm & __builtin_amdgcn_ballot_w64(h & ((tt < tmax) | ((tt == tmax) & (tk < hi))));
+                        if (STATS && lo == P.dbg_lo && hi == P.dbg_hi && ((bm >> P.dbg_ray) & 1ull) && lane == P.dbg_ray) {
+                            P.pairs_traced[4] = (unsigned long long)tk;
+                            P.pairs_traced[5] = (unsigned long long)__float_as_uint(tt);
+                            P.pairs_traced[6] = (unsigned long long)__float_as_uint(tmax);
+                            P.pairs_traced[7] = (unsigned long long)node;
+                        }
+                        blocked_m |= bm;
                     }
-                    alive_m &= ~(__builtin_amdgcn_ballot_w64(blocked) & hb_m);
+                    alive_m &= ~blocked_m;
                     if (alive_m == 0ull) break;
                 }
                 count += __popcll(alive_m);
+                if (STATS && lo == P.dbg_lo && hi == P.dbg_hi && lane == 0) P.pairs_traced[3] = alive_m;
             }
             if (lane == 0) sVis[i][j] = (unsigned char)count;
-            if (STATS && lane == 0) {
+            if (STATS && lane == 0 && P.dbg_lo < 0) {
                 atomicAdd(P.pairs_traced + 1, (unsigned long long)n_visit);
                 atomicAdd(P.pairs_traced + 2, (unsigned long long)n_leaf);
             }
@@ -584,7 +602,7 @@ static int tile_threads() {
 
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p) {
     dim3 grid(p.nT, p.nOwnedTiles);
-    if (p.stats) {
+    if (p.stats & 1) {
         hipLaunchKernelGGL((k_ff_tiles<256, true>), grid, dim3(256), 0, st, p);
         return hipGetLastError();
     }

@@ -165,6 +165,9 @@ int dr_synchronize(dr_context* ctx);
 /* tests: the threaded LBVH, n_bvh_nodes records of 32 bytes
  * {float lo[3], hi[3]; int32 skip; int32 patch (-1 = internal)} in pre-order */
 int dr_debug_read_bvh(dr_context* ctx, void* out, int max_nodes);
+/* tests: raw device arrays (0 TriRec[N] original order, 1 TriRec[N+2] Morton order,
+ * 3 the uploaded (u,v) samples, 4 PatchRec[N]) */
+int dr_debug_read_array(dr_context* ctx, int which, void* out, size_t bytes);
 
 #ifdef __cplusplus
 }

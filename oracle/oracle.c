@@ -184,13 +184,28 @@ void orc_uv2xyz(const orc_mesh* m, int tri, float u, float v, float out[3]) {
     out[0] = p.x; out[1] = p.y; out[2] = p.z;
 }
 
-/* ---- ray/triangle: the oracle's definition of the closed-source closest-hit --
- * Two-sided Moller-Trumbore on (a, e1=b-a, e2=c-a).  A hit needs u>=0, v>=0,
- * u+v<=1 and t>0 (the reference tests hit.t > 0, OptixPrimeFunctionality.cpp:208);
- * det==0 gives inf/NaN that fail those tests. */
-typedef struct { v3 a, e1, e2; } tri_rec;
+/* ---- visibility: the oracle's definition of the closed-source ray engine ---------------
+ * (PARITY UNPINNED here: OptiX Prime is absent; this is a definition, not a restatement.)
+ *
+ * A triangle k "is hit" by a ray segment [0, tmax] iff
+ *   (1) the segment passes the fp32 slab test against k's padded bounding box
+ *       (box of a, a+e1, a+e2, padded by pad = 1e-4f*extent + 1e-30f, extent = largest side of
+ *       the bounding box of all referenced vertices), and
+ *   (2) the two-sided Moller-Trumbore test on (a, e1=b-a, e2=c-a) reports u>=0, v>=0,
+ *       u+v<=1 and t>0 (the reference tests hit.t > 0, OptixPrimeFunctionality.cpp:208;
+ *       det==0 gives inf/NaN that fail those tests).
+ * Gate (1) makes "hit" a geometric notion: without it the fp32 noise of (2) on sliver or
+ * grazing triangles reports hits arbitrarily far from the triangle, which no spatial index
+ * could reproduce.  The slab test is monotone under box enlargement in fp32, so culling by
+ * enclosing boxes (the oracle's BVH below, the product's LBVH) is exact, not approximate.
+ *
+ * Ray k of pair (lo,hi) is VISIBLE iff hi is hit on [0,inf) at t_hi and no triangle is hit on
+ * [0,t_hi] with t < t_hi, or t == t_hi and a lower index -- i.e. the closest hit, ties to the
+ * lowest id, is hi (OptixPrimeFunctionality.cpp:205-211).  Every triangle takes part, the source
+ * included (OptiX has no tmin here; the ray starts 1e-6 along its direction, :194). */
+typedef struct { v3 a, e1, e2; float lo[3], hi[3]; } tri_rec;
 
-static inline int tri_hit(v3 o, v3 d, const tri_rec* T, float* t_out) {
+static inline int tri_mt(v3 o, v3 d, const tri_rec* T, float* t_out) {
     v3 p = v3_cross(d, T->e2);
     float det = v3_dot(T->e1, p);
     float inv = 1.0f / det;
@@ -203,20 +218,60 @@ static inline int tri_hit(v3 o, v3 d, const tri_rec* T, float* t_out) {
     return 0;
 }
 
+/* a zero direction component must not turn (plane - origin) * inv into 0*inf = NaN */
+static inline float safe_inv(float d) { return d == 0.0f ? 3.0e38f : 1.0f / d; }
+
+/* fp32 slab test of the segment [0,tmax]; every operation individually rounded, this order:
+ * max(tn,0) <= min(tf*1.00001f, tmax).  fminf/fmaxf drop NaNs like the GPU's v_min/v_max. */
+static inline int slab_hit(const float lo[3], const float hi[3], v3 o, v3 inv, float tmax) {
+    float t0 = (lo[0] - o.x) * inv.x, t1 = (hi[0] - o.x) * inv.x;
+    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+    t0 = (lo[1] - o.y) * inv.y; t1 = (hi[1] - o.y) * inv.y;
+    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+    t0 = (lo[2] - o.z) * inv.z; t1 = (hi[2] - o.z) * inv.z;
+    tn = fmaxf(fmaxf(tn, fminf(t0, t1)), 0.0f); tf = fminf(tf, fmaxf(t0, t1));
+    return tn <= fminf(tf * 1.00001f, tmax);
+}
+
+static inline int tri_hit(v3 o, v3 d, v3 inv, const tri_rec* T, float tmax, float* t_out) {
+    return slab_hit(T->lo, T->hi, o, inv, tmax) && tri_mt(o, d, T, t_out);
+}
+
+static float mesh_pad(const orc_mesh* m) {
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (long k = 0; k < 3L * m->N; k++) {
+        const float* p = m->vertices + 3 * (long)m->tri_v[k];
+        for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], p[a]); hi[a] = fmaxf(hi[a], p[a]); }
+    }
+    float ext = fmaxf(hi[0] - lo[0], fmaxf(hi[1] - lo[1], hi[2] - lo[2]));
+    return 1e-4f * ext + 1e-30f;
+}
+
 static tri_rec* tris_build(const orc_mesh* m) {
-    tri_rec* T = (tri_rec*)malloc(sizeof(tri_rec) * (size_t)m->N);
+    tri_rec* T = (tri_rec*)malloc(sizeof(tri_rec) * (size_t)(m->N > 0 ? m->N : 1));
+    const float pad = mesh_pad(m);
     for (int k = 0; k < m->N; k++) {
         v3 a = vert(m, k, 0), b = vert(m, k, 1), c = vert(m, k, 2);
         T[k].a = a; T[k].e1 = v3_sub(b, a); T[k].e2 = v3_sub(c, a);
+        /* the box of the triangle the ray test sees: a, a+e1, a+e2 */
+        float p[3][3] = { { a.x, a.y, a.z },
+                          { a.x + T[k].e1.x, a.y + T[k].e1.y, a.z + T[k].e1.z },
+                          { a.x + T[k].e2.x, a.y + T[k].e2.y, a.z + T[k].e2.z } };
+        for (int x = 0; x < 3; x++) {
+            T[k].lo[x] = fminf(p[0][x], fminf(p[1][x], p[2][x])) - pad;
+            T[k].hi[x] = fmaxf(p[0][x], fmaxf(p[1][x], p[2][x])) + pad;
+        }
     }
     return T;
 }
 
+/* closest hit on [0,inf), ties to the lowest id */
 static inline int closest_brute(const tri_rec* T, int N, v3 o, v3 d, float* t_out) {
     int best = -1; float bt = 0;
+    v3 inv = { safe_inv(d.x), safe_inv(d.y), safe_inv(d.z) };
     for (int k = 0; k < N; k++) {
         float t;
-        if (tri_hit(o, d, &T[k], &t) && (best < 0 || t < bt)) { best = k; bt = t; }
+        if (tri_hit(o, d, inv, &T[k], INFINITY, &t) && (best < 0 || t < bt)) { best = k; bt = t; }
     }
     *t_out = best >= 0 ? bt : -1.0f;
     return best;
@@ -245,9 +300,16 @@ static int vis_count_brute(const orc_mesh* m, const tri_rec* T, int lo, int hi,
                            const float* uv, int K, float eps) {
     int cnt = 0;
     for (int k = 0; k < K; k++) {
-        v3 o, d; float t;
+        v3 o, d; float t_hi;
         make_ray(m, lo, hi, uv[2 * k], uv[2 * k + 1], eps, &o, &d);
-        if (closest_brute(T, m->N, o, d, &t) == hi) cnt++;
+        v3 inv = { safe_inv(d.x), safe_inv(d.y), safe_inv(d.z) };
+        if (!tri_hit(o, d, inv, &T[hi], INFINITY, &t_hi)) continue;       /* the destination is not hit at all */
+        int blocked = 0;
+        for (int j = 0; j < m->N && !blocked; j++) {
+            float t;
+            if (tri_hit(o, d, inv, &T[j], t_hi, &t) && (t < t_hi || (t == t_hi && j < hi))) blocked = 1;
+        }
+        if (!blocked) cnt++;
     }
     return cnt;
 }
@@ -259,19 +321,10 @@ int orc_visibility_count(const orc_mesh* m, int lo, int hi, const float* uv, int
     return c;
 }
 
-/* ---- the oracle's own BVH (median split; closest hit with (t,id) order) ------ */
+/* ---- the oracle's own BVH (median split; node boxes = unions of the triangles' padded boxes,
+ * so culling is exact) --------------------------------------------------------------------- */
 typedef struct { float lo[3], hi[3]; int left, right, first, count; } bnode;
 typedef struct { bnode* nodes; int n_nodes; int* order; const tri_rec* T; } cbvh;
-
-static void tri_bounds(const tri_rec* t, float lo[3], float hi[3]) {
-    float p[3][3] = { { t->a.x, t->a.y, t->a.z },
-                      { t->a.x + t->e1.x, t->a.y + t->e1.y, t->a.z + t->e1.z },
-                      { t->a.x + t->e2.x, t->a.y + t->e2.y, t->a.z + t->e2.z } };
-    for (int a = 0; a < 3; a++) {
-        lo[a] = fminf(p[0][a], fminf(p[1][a], p[2][a]));
-        hi[a] = fmaxf(p[0][a], fmaxf(p[1][a], p[2][a]));
-    }
-}
 
 static const float* g_sort_key;
 static int cmp_key(const void* a, const void* b) {
@@ -279,16 +332,15 @@ static int cmp_key(const void* a, const void* b) {
     return (ka > kb) - (ka < kb);
 }
 
-static int bvh_build_rec(cbvh* B, int first, int count, float* cen, float pad) {
+static int bvh_build_rec(cbvh* B, int first, int count, float* cen) {
     int id = B->n_nodes++;
     bnode* nd = &B->nodes[id];
     for (int a = 0; a < 3; a++) { nd->lo[a] = INFINITY; nd->hi[a] = -INFINITY; }
     for (int i = first; i < first + count; i++) {
-        float lo[3], hi[3];
-        tri_bounds(&B->T[B->order[i]], lo, hi);
+        const tri_rec* t = &B->T[B->order[i]];
         for (int a = 0; a < 3; a++) {
-            nd->lo[a] = fminf(nd->lo[a], lo[a] - pad);
-            nd->hi[a] = fmaxf(nd->hi[a], hi[a] + pad);
+            nd->lo[a] = fminf(nd->lo[a], t->lo[a]);
+            nd->hi[a] = fmaxf(nd->hi[a], t->hi[a]);
         }
     }
     nd->first = first; nd->count = count; nd->left = nd->right = -1;
@@ -301,9 +353,8 @@ static int bvh_build_rec(cbvh* B, int first, int count, float* cen, float pad) {
             clo[a] = fminf(clo[a], c); chi[a] = fmaxf(chi[a], c);
         }
     for (int a = 0; a < 3; a++) if (chi[a] - clo[a] > ext) { ext = chi[a] - clo[a]; ax = a; }
-    float* key = (float*)malloc(sizeof(float) * (size_t)count);
-    /* sort this range by centroid along ax */
-    {
+    {   /* sort this range by centroid along ax */
+        float* key = (float*)malloc(sizeof(float) * (size_t)count);
         int* idx = (int*)malloc(sizeof(int) * (size_t)count);
         int* tmp = (int*)malloc(sizeof(int) * (size_t)count);
         for (int i = 0; i < count; i++) { key[i] = cen[3 * (long)B->order[first + i] + ax]; idx[i] = i; }
@@ -311,12 +362,11 @@ static int bvh_build_rec(cbvh* B, int first, int count, float* cen, float pad) {
         qsort(idx, (size_t)count, sizeof(int), cmp_key);
         for (int i = 0; i < count; i++) tmp[i] = B->order[first + idx[i]];
         memcpy(B->order + first, tmp, sizeof(int) * (size_t)count);
-        free(idx); free(tmp);
+        free(idx); free(tmp); free(key);
     }
-    free(key);
     int half = count / 2;
-    int l = bvh_build_rec(B, first, half, cen, pad);
-    int r = bvh_build_rec(B, first + half, count - half, cen, pad);
+    int l = bvh_build_rec(B, first, half, cen);
+    int r = bvh_build_rec(B, first + half, count - half, cen);
     B->nodes[id].left = l; B->nodes[id].right = r;
     return id;
 }
@@ -325,63 +375,44 @@ static cbvh bvh_build(const tri_rec* T, int N) {
     cbvh B;
     B.T = T; B.n_nodes = 0;
     B.nodes = (bnode*)malloc(sizeof(bnode) * (size_t)(2 * N + 1));
-    B.order = (int*)malloc(sizeof(int) * (size_t)N);
-    float* cen = (float*)malloc(sizeof(float) * 3 * (size_t)N);
-    float slo[3] = { INFINITY, INFINITY, INFINITY }, shi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    B.order = (int*)malloc(sizeof(int) * (size_t)(N > 0 ? N : 1));
+    float* cen = (float*)malloc(sizeof(float) * 3 * (size_t)(N > 0 ? N : 1));
     for (int k = 0; k < N; k++) {
-        float lo[3], hi[3];
-        tri_bounds(&T[k], lo, hi);
-        for (int a = 0; a < 3; a++) {
-            cen[3 * (long)k + a] = 0.5f * (lo[a] + hi[a]);
-            slo[a] = fminf(slo[a], lo[a]); shi[a] = fmaxf(shi[a], hi[a]);
-        }
+        for (int a = 0; a < 3; a++) cen[3 * (long)k + a] = 0.5f * (T[k].lo[a] + T[k].hi[a]);
         B.order[k] = k;
     }
-    float ext = fmaxf(shi[0] - slo[0], fmaxf(shi[1] - slo[1], shi[2] - slo[2]));
-    if (N > 0) bvh_build_rec(&B, 0, N, cen, 1e-4f * ext + 1e-30f);
+    if (N > 0) bvh_build_rec(&B, 0, N, cen);
     free(cen);
     return B;
 }
 static void bvh_free(cbvh* B) { free(B->nodes); free(B->order); }
 
-/* conservative slab test on [0, tmax] */
-static inline int box_hit(const bnode* nd, v3 o, v3 inv, float tmax) {
-    float t0 = (nd->lo[0] - o.x) * inv.x, t1 = (nd->hi[0] - o.x) * inv.x;
-    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
-    t0 = (nd->lo[1] - o.y) * inv.y; t1 = (nd->hi[1] - o.y) * inv.y;
-    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-    t0 = (nd->lo[2] - o.z) * inv.z; t1 = (nd->hi[2] - o.z) * inv.z;
-    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-    return tn <= tf * 1.00001f && tf >= 0.0f && tn <= tmax;
-}
-
-static int closest_bvh(const cbvh* B, v3 o, v3 d, float* t_out) {
-    int best = -1; float bt = INFINITY;
-    if (B->n_nodes == 0) { *t_out = -1.0f; return -1; }
-    v3 inv = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
+/* is any triangle hit on [0,t_hi] that precedes `hi`?  (the same predicate as the brute force) */
+static int blocked_bvh(const cbvh* B, v3 o, v3 d, v3 inv, float t_hi, int hi) {
+    if (B->n_nodes == 0) return 0;
     int stack[128]; int sp = 0; stack[sp++] = 0;
     while (sp) {
         const bnode* nd = &B->nodes[stack[--sp]];
-        if (!box_hit(nd, o, inv, bt)) continue;
+        if (!slab_hit(nd->lo, nd->hi, o, inv, t_hi)) continue;
         if (nd->left < 0) {
             for (int i = nd->first; i < nd->first + nd->count; i++) {
                 int k = B->order[i]; float t;
-                if (tri_hit(o, d, &B->T[k], &t) && (t < bt || (t == bt && k < best))) { best = k; bt = t; }
+                if (tri_hit(o, d, inv, &B->T[k], t_hi, &t) && (t < t_hi || (t == t_hi && k < hi))) return 1;
             }
         } else { stack[sp++] = nd->left; stack[sp++] = nd->right; }
     }
-    *t_out = best >= 0 ? bt : -1.0f;
-    return best;
+    return 0;
 }
 
 static int vis_count_bvh(const orc_mesh* m, const cbvh* B, int lo, int hi,
                          const float* uv, int K, float eps) {
     int cnt = 0;
     for (int k = 0; k < K; k++) {
-        v3 o, d; float t;
+        v3 o, d; float t_hi;
         make_ray(m, lo, hi, uv[2 * k], uv[2 * k + 1], eps, &o, &d);
-        if (d.x != d.x) continue; /* degenerate direction: brute force hits nothing either */
-        if (closest_bvh(B, o, d, &t) == hi) cnt++;
+        v3 inv = { safe_inv(d.x), safe_inv(d.y), safe_inv(d.z) };
+        if (!tri_hit(o, d, inv, &B->T[hi], INFINITY, &t_hi)) continue;
+        if (!blocked_bvh(B, o, d, inv, t_hi, hi)) cnt++;
     }
     return cnt;
 }
@@ -518,4 +549,25 @@ int orc_num_threads(void) {
 #else
     return 1;
 #endif
+}
+
+/* debug aid for tests: per ray of a pair, list triangles whose Moller-Trumbore test alone would block it */
+#include <stdio.h>
+void orc_debug_pair(const orc_mesh* m, int lo, int hi, const float* uv, int K, float eps) {
+    tri_rec* T = tris_build(m);
+    for (int k = 0; k < K; k++) {
+        v3 o, d; float t_hi = -1;
+        make_ray(m, lo, hi, uv[2 * k], uv[2 * k + 1], eps, &o, &d);
+        v3 inv = { safe_inv(d.x), safe_inv(d.y), safe_inv(d.z) };
+        int gate_hi = slab_hit(T[hi].lo, T[hi].hi, o, inv, INFINITY), mt_hi = tri_mt(o, d, &T[hi], &t_hi);
+        if (!(gate_hi && mt_hi)) { printf("ray %d: target gate %d mt %d\n", k, gate_hi, mt_hi); continue; }
+        for (int j = 0; j < m->N; j++) {
+            float t;
+            if (tri_mt(o, d, &T[j], &t) && (t < t_hi || (t == t_hi && j < hi)))
+                printf("ray %d: tri %d mt-blocks t=%.9g t_hi=%.9g gate=%d dir=(%.9g %.9g %.9g) org=(%.9g %.9g %.9g) box lo=(%.9g %.9g %.9g) hi=(%.9g %.9g %.9g)\n",
+                       k, j, t, t_hi, slab_hit(T[j].lo, T[j].hi, o, inv, t_hi), d.x, d.y, d.z, o.x, o.y, o.z,
+                       T[j].lo[0], T[j].lo[1], T[j].lo[2], T[j].hi[0], T[j].hi[1], T[j].hi[2]);
+        }
+    }
+    free(T);
 }

@@ -15,8 +15,10 @@
  *     closest-hit query is closed-source NVIDIA OptiX Prime 4.1.1
  *     (vs/OptixPrimeFunctionality.cpp:66-81), absent from /root/reference, and
  *     no reference test records its results.  The oracle defines it as an
- *     exact brute-force closest hit (Moller-Trumbore, fp32, every operation
- *     individually rounded, lowest triangle id wins ties).
+ *     exact brute-force closest hit: a triangle is hit iff the ray segment
+ *     passes the fp32 slab test against its padded bounding box AND the
+ *     Moller-Trumbore test (fp32, every operation individually rounded);
+ *     lowest triangle id wins ties (see oracle.c "visibility").
  *
  * All arithmetic is IEEE-754 binary32 unless a comment says otherwise, in the
  * written order, with contraction off (-ffp-contract=off).
@@ -68,8 +70,8 @@ void orc_integrand_rows(const orc_mesh* m, int row0, int nrows, float* out);
 /* uv2xyz, triangle_math.cpp:3-9 */
 void orc_uv2xyz(const orc_mesh* m, int tri, float u, float v, float out[3]);
 
-/* Brute-force closest hit over all N triangles. Returns triangle id or -1;
- * *t_out receives t (or -1). */
+/* Brute-force closest hit over all N triangles on [0,inf) (box-gated Moller-Trumbore, ties to the
+ * lowest id). Returns triangle id or -1; *t_out receives t (or -1). */
 int orc_closest_hit(const orc_mesh* m, const float org[3], const float dir[3],
                     float* t_out);
 

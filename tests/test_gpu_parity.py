@@ -446,3 +446,27 @@ def test_grazing_rays_along_a_shallow_bowl(uv50):
     assert (sub != 255).sum() > 100 and (sub[sub != 255] < 50).any()   # in-sheet pairs are traced, some blocked
     assert np.array_equal(vis, viso)
     assert np.array_equal(_bits(F), _bits(Fo))
+
+
+@pytest.mark.parametrize("seed,n,scale", [(1, 300, 1.0), (2, 500, 40.0), (3, 200, 1e-3)])
+def test_random_triangle_soup(seed, n, scale, uv50):
+    """general position: intersecting, overlapping, sliver and tiny triangles with arbitrary vertex
+    normals, at three scene scales -- ray counts and F against the brute-force oracle, exact"""
+    rs = np.random.RandomState(seed)
+    c0 = rs.random_sample((n, 1, 3)) * 2 - 1
+    size = rs.random_sample((n, 1, 1)) ** 3 * 0.6 + 1e-3
+    tri = (c0 + (rs.random_sample((n, 3, 3)) - 0.5) * size) * scale + 0.37 * scale
+    tri[::17, 2] = tri[::17, 1] + (tri[::17, 1] - tri[::17, 0]) * 1e-4       # slivers
+    v = tri.reshape(-1, 3).astype(np.float32)
+    tv = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    nrm = rs.normal(size=(64, 3)).astype(np.float32)
+    tn = rs.randint(0, 64, size=(n, 3)).astype(np.int32)
+    with api.Context(0) as c:
+        c.set_mesh(v, nrm, tv, tn)
+        c.assemble(uv50, keep_visibility=True)
+        vis, F = c.read_visibility(0, n), c.read_rows(0, n)
+    Fo, viso, _ = ob.assemble_rows(ob.Mesh(v, nrm, tv, tn), uv50, bvh=False)
+    traced = viso != 255
+    assert traced.sum() > n and (viso[traced] == 0).any() and (viso[traced] == 50).any()
+    assert np.array_equal(vis, viso), int((vis != viso).sum())
+    assert np.array_equal(_bits(F), _bits(Fo))
