@@ -83,7 +83,20 @@ def cpu_baselines(ctx, sc, uv, n_rows_sweep, n_rows_ff):
     ff = {"value": n2 * (N - 1) / dt2, "unit": "pairs/s", "cores": 1, "kind": "port",
           "sample": "%d rows x %d columns, integrand + %d rays per facing pair through the oracle's BVH, %.1f s"
                     % (n2, N, uv.shape[0], dt2)}
-    return sweep, ff
+    # the same two samples with OpenMP over rows on every host core (the reference itself has no threading)
+    cores = ob.num_threads()
+    B = np.zeros((n1, S), np.float32)
+    t = time.perf_counter()
+    ob.sweep_rows(F, sc.M, sc.mat_of_patch, R, B, row0=r0, threads=cores)
+    dt3 = time.perf_counter() - t
+    n3 = min(info.nrows, n2 * cores)
+    t = time.perf_counter()
+    ob.assemble_rows(m, uv, row0=r0, nrows=n3, want_vis=False, threads=cores, bvh=True)
+    dt4 = time.perf_counter() - t
+    allcores = {"cores": cores, "kind": "port", "iters_per_s": 1.0 / (dt3 * (N / n1)),
+                "pairs_per_s": n3 * (N - 1) / dt4,
+                "sample": "same row samples (%d sweep rows, %d assembly rows), OpenMP over rows, %.1f + %.1f s" % (n1, n3, dt3, dt4)}
+    return sweep, ff, allcores
 
 
 def main():
@@ -207,9 +220,10 @@ def main():
             "residual_sum_after_timed_passes": resid,
         }
         if world == 1 and not args.no_cpu_baseline:
-            sweep_cpu, ff_cpu = cpu_baselines(ctx, sc, uv, 65536, 2)
+            sweep_cpu, ff_cpu, allcores = cpu_baselines(ctx, sc, uv, 65536, 2)
             out["cpu_baseline"] = sweep_cpu
             out["cpu_baseline_formfactors"] = ff_cpu
+            out["cpu_baseline_all_cores"] = allcores
             out["formfactors"]["vs_cpu_port"] = out["formfactors"]["value"] / ff_cpu["value"]
         print(json.dumps(out), flush=True)
     ctx.close()

@@ -470,3 +470,43 @@ def test_random_triangle_soup(seed, n, scale, uv50):
     assert traced.sum() > n and (viso[traced] == 0).any() and (viso[traced] == 50).any()
     assert np.array_equal(vis, viso), int((vis != viso).sum())
     assert np.array_equal(_bits(F), _bits(Fo))
+
+
+def test_bench_size_64k_properties(uv50):
+    """BASELINE.json's metric size (65 536 patches, 8 bins) on one GPU: spot rows against the oracle
+    (exact) and the size-independent properties of the matrix and of the passes"""
+    sc = scenes.cornell_box(65536, S=8)
+    N = sc.N
+    E = sc.emission(7.0)
+    m = _mesh(sc)
+    with _ctx(sc) as c:
+        c.assemble(uv50, keep_visibility=True)
+        info = c.info()
+        assert info.bytes_F == 4 * N * N
+        for r in (0, 31111, N - 2):
+            Fo, viso, _ = ob.assemble_rows(m, uv50, row0=r, nrows=2, bvh=True)
+            assert np.array_equal(c.read_visibility(r, 2), viso), r
+            assert np.array_equal(_bits(c.read_rows(r, 2)), _bits(Fo)), r
+        # transpose symmetry of the ray counts on a block far from the diagonal
+        va, vb = c.read_visibility(1000, 64)[:, 40000:40064], c.read_visibility(40000, 64)[:, 1000:1064]
+        assert np.array_equal(va, vb.T)
+        rows = c.read_rows(20000, 256)
+        assert np.isfinite(rows).all() and (rows >= 0).all()
+        assert np.all(rows[np.arange(256), 20000 + np.arange(256)] == 0)
+        assert 0.9 < rows.sum(axis=1).mean() < 1.1                      # closed room
+        c.solver_init(E, sc.M, sc.mat_of_patch)
+        sums = [c.step(1, want_sum=True) for _ in range(5)]
+        assert all(b < a for a, b in zip(sums, sums[1:]))               # energy decays, rho < 1
+        B, R = c.read()
+        c.solver_init(3 * E, sc.M, sc.mat_of_patch)
+        c.step(5)
+        B3, R3 = c.read()
+        assert np.allclose(R3, 3 * R, rtol=1e-5, atol=1e-12) and np.allclose(B3, 3 * B, rtol=1e-5, atol=1e-12)
+        # one pass against the oracle on a row sample of the same F
+        c.solver_init(E, sc.M, sc.mat_of_patch)
+        c.step(1)
+        _, R1 = c.read()
+        Fs = c.read_rows(50000, 64)
+        Bo = E[50000:50064].copy()
+        Ro = ob.sweep_rows(Fs, sc.M, sc.mat_of_patch, E, Bo, row0=50000)
+        assert (np.abs(R1[50000:50064] - Ro) / (np.abs(Ro).max(axis=0) + 1e-30)).max() < 2e-5
