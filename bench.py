@@ -84,12 +84,13 @@ def cpu_baselines(ctx, sc, uv, n_rows_sweep, n_rows_ff):
           "sample": "%d rows x %d columns, integrand + %d rays per facing pair through the oracle's BVH, %.1f s"
                     % (n2, N, uv.shape[0], dt2)}
     # the same two samples with OpenMP over rows on every host core (the reference itself has no threading)
-    cores = ob.num_threads()
+    # (a one-GPU box grants about 16 host CPUs however many the machine has: more threads only thrash)
+    cores = max(1, min(ob.num_threads(), len(os.sched_getaffinity(0)), 16))
     B = np.zeros((n1, S), np.float32)
     t = time.perf_counter()
     ob.sweep_rows(F, sc.M, sc.mat_of_patch, R, B, row0=r0, threads=cores)
     dt3 = time.perf_counter() - t
-    n3 = min(info.nrows, n2 * cores)
+    n3 = min(info.nrows, cores)
     t = time.perf_counter()
     ob.assemble_rows(m, uv, row0=r0, nrows=n3, want_vis=False, threads=cores, bvh=True)
     dt4 = time.perf_counter() - t
