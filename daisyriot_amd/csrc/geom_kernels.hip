@@ -391,6 +391,69 @@ __device__ __forceinline__ void integrand_pair(const float* ri, const float* rj,
     fb = stored(accB / rj[19]);
 }
 
+// Walk of the threaded BVH for one wave of rays (segments [0,tmax] from org along dn); returns the
+// liveness mask with every lane cleared whose closest hit is not its destination `hi` (wave-uniform
+// int in the one-pair-per-wave path, per-lane int in the packed path).
+template <bool STATS, typename HiT>
+__device__ __forceinline__ unsigned long long walk_bvh(const BvhNode* __restrict__ bvh, const TriRec* __restrict__ tri_sorted,
+                                                       int n_nodes_i, f3 org, f3 dn, f3 inv, float tmax, HiT hi,
+                                                       unsigned long long alive_m, int& n_visit, int& n_leaf) {
+    // Walk the threaded BVH with a wave-uniform node index.  The scalar unit (one per CU)
+    // carries as many instructions as the vector units here, so the step is kept minimal:
+    // one scalar node load at an SGPR offset, one slab test ending in a single v_cmp, one
+    // s_and with the liveness mask; the "any lane still alive" test only runs after a leaf
+    // could have retired lanes.  Every step moves forward in pre-order, so the walk ends.
+    const unsigned n_nodes = (unsigned)n_nodes_i;
+    unsigned node = (alive_m == 0ull) ? n_nodes : 0u;
+    while (node < n_nodes) {
+        // the whole 32-byte node in one scalar load (field-wise loads would chain latencies)
+        // (float vector + __float_as_int: __builtin_bit_cast on a vector ELEMENT reads element 0)
+        // base + 32-bit byte offset: selects the SGPR-offset form of s_load (no 64-bit address math)
+        const v8f raw = *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(bvh) + node * 32u);
+        BvhNode nd;
+        nd.lo[0] = raw[0]; nd.lo[1] = raw[1]; nd.lo[2] = raw[2];
+        nd.hi[0] = raw[3]; nd.hi[1] = raw[4]; nd.hi[2] = raw[5];
+        const int nd_skip = __builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
+        const int leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
+        if (STATS) n_visit++;
+        // the slab test runs for every lane, dead ones are masked after
+        const unsigned long long hb_m = box_hit_mask(nd.lo, nd.hi, org, inv, tmax) & alive_m;
+        if (hb_m == 0ull) { node = max((unsigned)nd_skip, node + 1u); continue; }
+        node = node + 1;
+        if (leaf < 0) continue;
+        if (STATS) n_leaf++;
+        const int first = leaf >> 3, cnt = (leaf & 7) + 1;
+        // Leaf: its LEAF_MAX records (64 B each: triangle, id, gate box) are fetched together --
+        // no dependent loads inside the leaf; a triangle's Moller-Trumbore test only runs when some
+        // live lane passes its gate.  The destination itself needs no exclusion: its t equals tmax
+        // bit for bit and its id is not lower than its own.
+        const v4f* tp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(tri_sorted) + (unsigned)first * 64u);
+        v4f q[4 * LEAF_MAX];
+#pragma unroll
+        for (int c = 0; c < 4 * LEAF_MAX; c++) q[c] = tp[c];
+        unsigned long long blocked_m = 0ull;
+#pragma unroll
+        for (int c = 0; c < LEAF_MAX; c++) {
+            const v4f A = q[4 * c], B = q[4 * c + 1], C3 = q[4 * c + 2], D = q[4 * c + 3];
+            const float blo[3] = { C3[2], C3[3], D[0] }, bhi[3] = { D[1], D[2], D[3] };
+            const unsigned long long gm = box_hit_mask(blo, bhi, org, inv, tmax) & alive_m;
+            if (gm == 0ull || c >= cnt) continue;      // (slots past the leaf's count belong to the next leaf)
+            const int tk = __builtin_amdgcn_readfirstlane(__float_as_int(C3[1]));
+            const f3 ta = f3{ A[0], A[1], A[2] };
+            const f3 te1 = f3{ A[3], B[0], B[1] };
+            const f3 te2 = f3{ B[2], B[3], C3[0] };
+            float tt;
+            const bool h = tri_hit(org, dn, ta, te1, te2, tt);
+            // closest hit is not `hi`: something nearer, or an equal-t hit of lower id
+            const unsigned long long bm = gm & __builtin_amdgcn_ballot_w64(h & ((tt < tmax) | ((tt == tmax) & (tk < hi))));
+            blocked_m |= bm;
+        }
+        alive_m &= ~blocked_m;
+        if (alive_m == 0ull) break;
+    }
+    return alive_m;
+}
+
 // STATS builds count BVH visits with global atomics inside the pair loop; that store makes
 // the compiler give up scalar (SMEM) loads for nodes and triangles, so it is a separate,
 // debug-only instantiation.
@@ -480,68 +543,9 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
                 // the destination must be hit at all: its gate on [0,inf) and the triangle test
                 if (alive) alive = tri_hit(org, dn, ha, he1, he2, tmax);
                 alive = alive && ((box_hit_mask(Th.lo, Th.hi, org, inv, INFINITY) >> lane) & 1ull);
-                // Walk the threaded BVH with a wave-uniform node index.  The scalar unit (one per CU)
-                // carries as many instructions as the vector units here, so the step is kept minimal:
-                // one scalar node load at an SGPR offset, one slab test ending in a single v_cmp, one
-                // s_and with the liveness mask; the "any lane still alive" test only runs after a leaf
-                // could have retired lanes.  Every step moves forward in pre-order, so the walk ends.
-                const unsigned n_nodes = (unsigned)P.n_nodes;
-                // liveness as an explicit wave mask in SGPRs: no per-step ballot
                 unsigned long long alive_m = __builtin_amdgcn_ballot_w64(alive);
                 if (STATS && lo == P.dbg_lo && hi == P.dbg_hi && lane == 0) P.pairs_traced[1] = alive_m;
-                unsigned node = (alive_m == 0ull) ? n_nodes : 0u;
-                while (node < n_nodes) {
-                    // the whole 32-byte node in one scalar load (field-wise loads would chain latencies)
-                    // (float vector + __float_as_int: __builtin_bit_cast on a vector ELEMENT reads element 0)
-                    // base + 32-bit byte offset: selects the SGPR-offset form of s_load (no 64-bit address math)
-                    const v8f raw = *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(P.bvh) + node * 32u);
-                    BvhNode nd;
-                    nd.lo[0] = raw[0]; nd.lo[1] = raw[1]; nd.lo[2] = raw[2];
-                    nd.hi[0] = raw[3]; nd.hi[1] = raw[4]; nd.hi[2] = raw[5];
-                    const int nd_skip = __builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
-                    const int leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
-                    if (STATS) n_visit++;
-                    // the slab test runs for every lane, dead ones are masked after
-                    const unsigned long long hb_m = box_hit_mask(nd.lo, nd.hi, org, inv, tmax) & alive_m;
-                    if (hb_m == 0ull) { node = max((unsigned)nd_skip, node + 1u); continue; }
-                    node = node + 1;
-                    if (leaf < 0) continue;
-                    if (STATS) n_leaf++;
-                    const int first = leaf >> 3, cnt = (leaf & 7) + 1;
-                    // Leaf: its LEAF_MAX records (64 B each: triangle, id, gate box) are fetched together --
-                    // no dependent loads inside the leaf; a triangle's Moller-Trumbore test only runs when some
-                    // live lane passes its gate.  The destination itself needs no exclusion: its t equals tmax
-                    // bit for bit and its id is not lower than its own.
-                    const v4f* tp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(P.tri_sorted) + (unsigned)first * 64u);
-                    v4f q[4 * LEAF_MAX];
-#pragma unroll
-                    for (int c = 0; c < 4 * LEAF_MAX; c++) q[c] = tp[c];
-                    unsigned long long blocked_m = 0ull;
-#pragma unroll
-                    for (int c = 0; c < LEAF_MAX; c++) {
-                        const v4f A = q[4 * c], B = q[4 * c + 1], C3 = q[4 * c + 2], D = q[4 * c + 3];
-                        const float blo[3] = { C3[2], C3[3], D[0] }, bhi[3] = { D[1], D[2], D[3] };
-                        const unsigned long long gm = box_hit_mask(blo, bhi, org, inv, tmax) & alive_m;
-                        if (gm == 0ull || c >= cnt) continue;      // (slots past the leaf's count belong to the next leaf)
-                        const int tk = __builtin_amdgcn_readfirstlane(__float_as_int(C3[1]));
-                        const f3 ta = f3{ A[0], A[1], A[2] };
-                        const f3 te1 = f3{ A[3], B[0], B[1] };
-                        const f3 te2 = f3{ B[2], B[3], C3[0] };
-                        float tt;
-                        const bool h = tri_hit(org, dn, ta, te1, te2, tt);
-                        // closest hit is not `hi`: something nearer, or an equal-t hit of lower id
-                        const unsigned long long bm = gm & __builtin_amdgcn_ballot_w64(h & ((tt < tmax) | ((tt == tmax) & (tk < hi))));
-                        if (STATS && lo == P.dbg_lo && hi == P.dbg_hi && ((bm >> P.dbg_ray) & 1ull) && lane == P.dbg_ray) {
-                            P.pairs_traced[4] = (unsigned long long)tk;
-                            P.pairs_traced[5] = (unsigned long long)__float_as_uint(tt);
-                            P.pairs_traced[6] = (unsigned long long)__float_as_uint(tmax);
-                            P.pairs_traced[7] = (unsigned long long)node;
-                        }
-                        blocked_m |= bm;
-                    }
-                    alive_m &= ~blocked_m;
-                    if (alive_m == 0ull) break;
-                }
+                alive_m = walk_bvh<STATS>(P.bvh, P.tri_sorted, P.n_nodes, org, dn, inv, tmax, hi, alive_m, n_visit, n_leaf);
                 count += __popcll(alive_m);
                 if (STATS && lo == P.dbg_lo && hi == P.dbg_hi && lane == 0) P.pairs_traced[3] = alive_m;
             }
