@@ -2,7 +2,8 @@
 // same config.ini keys, loads the same .obj/.mtl scene through MeshS, builds the Lightning the
 // ini selects, converges it, and writes the per-patch result instead of opening a window.
 //
-//   daisyriot_cli [config.ini] [--passes n] [--out file.csv] [--device d] [--no-matfile]
+//   daisyriot_cli [config.ini] [--passes n] [--out file.csv] [--ply file.ply] [--device d] [--no-matfile]
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -17,12 +18,13 @@
 using namespace daisy;
 
 int main(int argc, char** argv) {
-    std::string ini = "config.ini", out;
+    std::string ini = "config.ini", out, ply;
     int extra_passes = 0, device = 0;
     bool use_matfile = true;
     for (int a = 1; a < argc; a++) {
         if (!std::strcmp(argv[a], "--passes") && a + 1 < argc) extra_passes = std::atoi(argv[++a]);
         else if (!std::strcmp(argv[a], "--out") && a + 1 < argc) out = argv[++a];
+        else if (!std::strcmp(argv[a], "--ply") && a + 1 < argc) ply = argv[++a];
         else if (!std::strcmp(argv[a], "--device") && a + 1 < argc) device = std::atoi(argv[++a]);
         else if (!std::strcmp(argv[a], "--no-matfile")) use_matfile = false;
         else ini = argv[a];
@@ -73,6 +75,25 @@ int main(int argc, char** argv) {
                 for (int s = 0; s < S; s++) f << "," << B[(size_t)i * S + s];
                 f << "\n";
             }
+        }
+        if (!ply.empty()) {
+            // what the reference shows on screen, without a screen: every vertex gets the mean display colour of
+            // the patches around it -- the corner values Drawer::interpolate blends (Drawer.cpp:161-186)
+            std::ofstream f(ply.c_str());
+            f << "ply\nformat ascii 1.0\nelement vertex " << mesh.vertices.size()
+              << "\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n"
+              << "element face " << mesh.numtriangles << "\nproperty list uchar int vertex_indices\nend_header\n";
+            for (size_t v = 0; v < mesh.vertices.size(); v++) {
+                vec3 c{ 0, 0, 0 };
+                for (int t : mesh.trianglesPerVertex[v]) { vec3 p = lightning->get_color_of_patch(t); c.x += p.x; c.y += p.y; c.z += p.z; }
+                float n = (float)std::max<size_t>(1, mesh.trianglesPerVertex[v].size());
+                auto to8 = [](float x) { x = x < 0 ? 0 : (x > 1 ? 1 : x); return (int)(x * 255.0f + 0.5f); };
+                f << mesh.vertices[v].x << " " << mesh.vertices[v].y << " " << mesh.vertices[v].z << " "
+                  << to8(c.x / n) << " " << to8(c.y / n) << " " << to8(c.z / n) << "\n";
+            }
+            for (int t = 0; t < mesh.numtriangles; t++)
+                f << "3 " << mesh.triangleIndices[(size_t)t].vertex.x << " " << mesh.triangleIndices[(size_t)t].vertex.y << " "
+                  << mesh.triangleIndices[(size_t)t].vertex.z << "\n";
         }
     } catch (const std::exception& e) {
         std::cerr << "error: " << e.what() << std::endl;

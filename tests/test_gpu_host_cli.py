@@ -83,8 +83,15 @@ def test_f_cache_round_trip_and_extra_passes(tmp_path):
     out2, d2 = _run(tmp_path)
     assert "Deserialized matrix" in out2
     assert np.array_equal(d1, d2)
-    out3, d3 = _run(tmp_path, "--passes", "3")                                # three presses of 'L'
+    out3, d3 = _run(tmp_path, "--passes", "3", "--ply", str(tmp_path / "view.ply"))   # three presses of 'L'
     assert (d3[:, 4:] >= d2[:, 4:]).all() and (d3[:, 4:] > d2[:, 4:]).any()
+    # vertex-averaged display colours (the corner values of Drawer::interpolate) as a viewable mesh
+    ply = (tmp_path / "view.ply").read_text().splitlines()
+    nv = int([l for l in ply if l.startswith("element vertex")][0].split()[-1])
+    body = ply[ply.index("end_header") + 1:]
+    assert len(body) == nv + 300 and all(0 <= int(x) <= 255 for x in body[0].split()[3:6])
+    cols = np.array([[int(x) for x in l.split()[3:6]] for l in body[:nv]])
+    assert cols.max() > 50                                                     # the lamp lights the room
 
 
 def test_spectral_and_bw_methods_run(tmp_path):
