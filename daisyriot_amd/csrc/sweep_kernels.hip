@@ -22,7 +22,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // SPLIT: the columns are cut into gridDim.y ranges (small row shards would otherwise leave most
 // CUs with one block or none); each block then writes its partial sums and k_sweep_epilogue adds
 // them in a fixed order and applies the bin transfer.
-template <int S, int RR, int NW, int CPL, bool NT, int OCC, bool SPLIT>
+template <int S, int RR, int NW, int CPL, bool NT, int OCC, bool SPLIT, int LOOKAHEAD = 0>
 __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
     constexpr int TC = 256 * CPL;
     __shared__ __attribute__((aligned(16))) float sR[2][S][TC];
@@ -76,13 +76,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
             }
         }
     };
+    // wave-uniform row base (SGPR pair) + one 32-bit per-lane byte offset shared by all rows: the
+    // saddr form of global_load, no 64-bit per-row addresses in VGPRs
     auto load_f = [&](int tl, v4f (&dst)[RR][CPL]) {
-        const int t = tile0 + tl;
+        const unsigned voff = (unsigned)(tile0 + tl) * (unsigned)(TC * 4) + (unsigned)lane * 16u;
 #pragma unroll
         for (int r = 0; r < RR; r++)
 #pragma unroll
             for (int c = 0; c < CPL; c++) {
-                const v4f* p = reinterpret_cast<const v4f*>(frow[r] + (size_t)t * TC + c * 256 + lane * 4);
+                const v4f* p = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(frow[r]) + (voff + (unsigned)(c * 1024)));
                 dst[r][c] = NT ? __builtin_nontemporal_load(p) : *p;
             }
     };
@@ -104,19 +106,45 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
             load_rtile(tt);
         }
         const int buf = t & 1;
+        if (LOOKAHEAD == 0) {
 #pragma unroll
-        for (int c = 0; c < CPL; c++)
+            for (int c = 0; c < CPL; c++)
 #pragma unroll
-            for (int s = 0; s < S; s++) {
-                const v4f x = *reinterpret_cast<const v4f*>(&sR[buf][s][c * 256 + lane * 4]);
+                for (int s = 0; s < S; s++) {
+                    const v4f x = *reinterpret_cast<const v4f*>(&sR[buf][s][c * 256 + lane * 4]);
 #pragma unroll
-                for (int r = 0; r < RR; r++) {
-                    acc[r][s] = fmaf(fcur[r][c].x, x.x, acc[r][s]);
-                    acc[r][s] = fmaf(fcur[r][c].y, x.y, acc[r][s]);
-                    acc[r][s] = fmaf(fcur[r][c].z, x.z, acc[r][s]);
-                    acc[r][s] = fmaf(fcur[r][c].w, x.w, acc[r][s]);
+                    for (int r = 0; r < RR; r++) {
+                        acc[r][s] = fmaf(fcur[r][c].x, x.x, acc[r][s]);
+                        acc[r][s] = fmaf(fcur[r][c].y, x.y, acc[r][s]);
+                        acc[r][s] = fmaf(fcur[r][c].z, x.z, acc[r][s]);
+                        acc[r][s] = fmaf(fcur[r][c].w, x.w, acc[r][s]);
+                    }
+                }
+        } else {
+            // residual values are read LOOKAHEAD bins ahead of their use and the scheduler is fenced per bin,
+            // so the compiler cannot hoist all S LDS reads (4 VGPRs each) to the top of the tile
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                v4f xq[LOOKAHEAD + 1];
+#pragma unroll
+                for (int a = 0; a < LOOKAHEAD; a++)
+                    if (a < S) xq[a] = *reinterpret_cast<const v4f*>(&sR[buf][a][c * 256 + lane * 4]);
+#pragma unroll
+                for (int s = 0; s < S; s++) {
+                    if (s + LOOKAHEAD < S)
+                        xq[(s + LOOKAHEAD) % (LOOKAHEAD + 1)] = *reinterpret_cast<const v4f*>(&sR[buf][s + LOOKAHEAD][c * 256 + lane * 4]);
+                    const v4f x = xq[s % (LOOKAHEAD + 1)];
+#pragma unroll
+                    for (int r = 0; r < RR; r++) {
+                        acc[r][s] = fmaf(fcur[r][c].x, x.x, acc[r][s]);
+                        acc[r][s] = fmaf(fcur[r][c].y, x.y, acc[r][s]);
+                        acc[r][s] = fmaf(fcur[r][c].z, x.z, acc[r][s]);
+                        acc[r][s] = fmaf(fcur[r][c].w, x.w, acc[r][s]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+        }
         if (more) store_rtile(buf ^ 1);
         __syncthreads();
 #pragma unroll
@@ -167,6 +195,143 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFMA variant for 9..16 bins.  With RR*S accumulators per lane the VALU kernel above runs out of
+// registers beyond 8 bins (S = 9: 71 %, S = 16: 56 % of the HBM peak).  Here a wave owns 16 rows and
+// one v_mfma_f32_16x16x4_f32 accumulator tile (rows x 16 padded bins = 4 registers per lane):
+//   D[row][bin] += sum_k A[row][k] * B[k][bin],  A = 16 rows x 4 columns of F, B = 4 columns x 16 bins of R.
+// The f32 MFMA runs at the VALU FMA rate -- it is used for its register economy, not for FLOPs.
+// F never passes through VGPRs: each wave streams its own 16 x 128 tile into LDS with
+// global_load_lds_dwordx4 (1 KiB per wave-instruction, non-temporal), double buffered; the source
+// chunk order is XOR-swizzled by the row so that the row-strided ds_read_b128 of the A operand is
+// bank-conflict free.  The k order inside a tile is permuted (lane group g, component c <-> column
+// 16m + 4g + c) identically for A and B, which a sum over k does not see.
+constexpr int MT_TC = 128;      // columns per tile
+constexpr int MT_ROWS = 16;     // rows per wave
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <int NW, bool SPLIT>
+__global__ __launch_bounds__(NW * 64) void k_sweep_mfma(SweepParams P) {
+    __shared__ __attribute__((aligned(16))) float sF[NW][2][MT_ROWS * MT_TC];      // 16 KiB per wave
+    __shared__ __attribute__((aligned(16))) float sRt[(MT_TC / 4) * 16 * 4];       // [chunk][bin][4 columns], 8 KiB
+    __shared__ float sG[NW][MT_ROWS][16];
+
+    const int S = P.S;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rbase = (blockIdx.x * NW + wave) * MT_ROWS;
+    const int ntiles_all = (P.world * P.rpr) / MT_TC;
+    const int ntiles = SPLIT ? ntiles_all / (int)gridDim.y : ntiles_all;
+    const int tile0 = SPLIT ? (int)blockIdx.y * ntiles : 0;
+    const int tiles_per_chunk = P.rpr / MT_TC;
+
+    // bins S..15 of the residual tile are zero and never rewritten
+    for (int x = tid; x < (MT_TC / 4) * 16; x += NW * 64)
+        if ((x & 15) >= S) *reinterpret_cast<v4f*>(&sRt[x * 4]) = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+
+    // per-lane source rows of the eight DMA instructions of a tile (two rows per instruction)
+    const int p_in_row = lane & 31;
+    auto dma_f = [&](int tl, int b) {
+        const size_t col0 = (size_t)(tile0 + tl) * MT_TC;
+#pragma unroll
+        for (int n = 0; n < 8; n++) {
+            const int row_l = 2 * n + (lane >> 5);
+            const int chunk = p_in_row ^ row_l;                   // source swizzle (row_l < 16, chunk < 32)
+            const int grow = min(rbase + row_l, P.nrows - 1);
+            const float* g = P.F + (size_t)grow * P.ldF + col0 + chunk * 4;
+            // Issued as inline asm on purpose: with the builtin hipcc treats the DMA as an LDS store that may
+            // alias the tile being read and drains it (vmcnt(0)) before the first ds_read of the CURRENT
+            // tile, i.e. no overlap.  M0 = LDS byte address of this 1 KiB piece; lane i lands at +16*i.
+            const unsigned lds_addr = (unsigned)(size_t)(lds_ptr_t)(&sF[wave][b][n * 256]);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt"
+                         :: "s"(lds_addr), "v"(g) : "memory", "m0");
+        }
+    };
+    constexpr int R4 = ((MT_TC / 4) * 16 + NW * 64 - 1) / (NW * 64);
+    v4f rreg[R4];
+    auto load_r = [&](int tl) {
+        const int t = tile0 + tl;
+        const int chunk_rank = t / tiles_per_chunk;
+        const int l0 = (t - chunk_rank * tiles_per_chunk) * MT_TC;
+        const float* base = P.Rin + (size_t)chunk_rank * S * P.rpr + l0;
+#pragma unroll
+        for (int x = 0; x < R4; x++) {
+            const int q = tid + x * NW * 64;                      // s = q / 32, 4-column chunk = q % 32
+            if (q < (MT_TC / 4) * S) rreg[x] = *reinterpret_cast<const v4f*>(base + (size_t)(q >> 5) * P.rpr + (q & 31) * 4);
+        }
+    };
+    auto store_r = [&]() {
+#pragma unroll
+        for (int x = 0; x < R4; x++) {
+            const int q = tid + x * NW * 64;
+            if (q < (MT_TC / 4) * S) *reinterpret_cast<v4f*>(&sRt[((q & 31) * 16 + (q >> 5)) * 4]) = rreg[x];
+        }
+    };
+
+    int tt = (int)(((unsigned)blockIdx.x * (unsigned)P.skew) % (unsigned)ntiles);
+    load_r(tt);
+    dma_f(tt, 0);
+    store_r();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the asm DMAs are invisible to the compiler's counters
+    __syncthreads();
+
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc0 = { 0, 0, 0, 0 }, acc1 = { 0, 0, 0, 0 };
+    const int r = lane & 15, g = lane >> 4;
+    for (int t = 0; t < ntiles; t++) {
+        const bool more = (t + 1) < ntiles;
+        tt = (tt + 1 == ntiles) ? 0 : tt + 1;
+        if (more) {
+            load_r(tt);
+            dma_f(tt, (t + 1) & 1);
+        }
+        const float* f = sF[wave][t & 1];
+#pragma unroll
+        for (int m = 0; m < MT_TC / 16; m++) {
+            const int c = 4 * m + g;                               // 4-column chunk of this lane group
+            const v4f fq = *reinterpret_cast<const v4f*>(&f[r * MT_TC + ((c ^ r) << 2)]);
+            const v4f rq = *reinterpret_cast<const v4f*>(&sRt[(c * 16 + r) * 4]);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fq[0], rq[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fq[1], rq[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fq[2], rq[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fq[3], rq[3], acc1, 0, 0, 0);
+        }
+        __syncthreads();                 // everyone is done with this residual tile
+        // the next tile's DMA had the whole compute phase to land; it must be complete (and the next
+        // residual tile stored) before anyone reads either
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (more) store_r();
+        __syncthreads();
+    }
+    // C/D layout of the 16x16 tile: column (bin) = lane & 15, row = (lane >> 4) * 4 + register
+#pragma unroll
+    for (int k = 0; k < 4; k++) sG[wave][g * 4 + k][r] = acc0[k] + acc1[k];
+    __syncthreads();
+
+    if (SPLIT) {
+        for (int e = lane; e < MT_ROWS * S; e += 64) {
+            const int rr = e / S, s = e % S;
+            const int row = rbase + rr;
+            if (row < P.nrows) P.Gpart[((size_t)blockIdx.y * P.nrows + row) * S + s] = sG[wave][rr][s];
+        }
+        return;
+    }
+    for (int e = lane; e < MT_ROWS * S; e += 64) {
+        const int so = e / MT_ROWS, rr = e % MT_ROWS;      // consecutive lanes -> consecutive rows of one bin
+        const int row = rbase + rr;
+        if (row < P.nrows) {
+            const float* Mi = P.M + (size_t)P.mat[row] * S * S + so * S;
+            float v = 0.0f;
+            for (int s = 0; s < S; s++) v = fmaf(Mi[s], sG[wave][rr][s], v);
+            P.Rout[((size_t)P.rank * S + so) * P.rpr + row] = v;
+            float* b = P.B + (size_t)so * P.rpr + row;
+            *b = *b + v;
+        }
+    }
+}
+
 // sums the column-split partials in split order and applies M (one thread per row and output bin)
 template <int S>
 __global__ void k_sweep_epilogue(SweepParams P) {
@@ -190,17 +355,17 @@ __global__ void k_sweep_epilogue(SweepParams P) {
     *b = *b + v;
 }
 
-template <int S, int RR, int NW, int CPL, bool NT, int OCC = 1>
+template <int S, int RR, int NW, int CPL, bool NT, int OCC = 1, int LOOKAHEAD = 0>
 static hipError_t launch_cfg(hipStream_t st, const SweepParams& p) {
     const int rows_per_block = RR * NW;
     dim3 grid((p.nrows + rows_per_block - 1) / rows_per_block, p.ksplit);
     if (p.ksplit > 1) {
-        hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC, true>), grid, dim3(NW * 64), 0, st, p);
+        hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC, true, LOOKAHEAD>), grid, dim3(NW * 64), 0, st, p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_sweep_epilogue<S>), dim3((p.nrows * S + 255) / 256), dim3(256), 0, st, p);
     } else {
-        hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC, false>), grid, dim3(NW * 64), 0, st, p);
+        hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC, false, LOOKAHEAD>), grid, dim3(NW * 64), 0, st, p);
     }
     return hipGetLastError();
 }
@@ -210,8 +375,8 @@ static hipError_t launch_cfg(hipStream_t st, const SweepParams& p) {
 // keeping at least 16 tiles; the count must divide the tile count.  Measured at N = 65 536 on one
 // MI355X (profiles/r01/sweep_shards.md): 8192 rows 0.437 ms unsplit -> 0.342 ms with 4 ranges.
 int sweep_ksplit(int nrows, int S, int total_cols) {
-    const int rr = (S <= 8) ? 8 : 4;
-    const int row_blocks = (nrows + rr * 4 - 1) / (rr * 4);
+    const int rows_per_block = (S <= 8) ? 32 : 4 * MT_ROWS;      // k_sweep: 4 waves x 8 rows; k_sweep_mfma: 4 x 16
+    const int row_blocks = (nrows + rows_per_block - 1) / rows_per_block;
     const int ntiles = total_cols / 256;
     static int forced = -2;
     if (forced == -2) { const char* e = getenv("DR_SWEEP_KSPLIT"); forced = e ? atoi(e) : -1; }
@@ -236,12 +401,38 @@ static int sweep_cfg() {
     return cfg;
 }
 
+template <int S>
+static void launch_epilogue_s(hipStream_t st, const SweepParams& p) {
+    hipLaunchKernelGGL((k_sweep_epilogue<S>), dim3((p.nrows * S + 255) / 256), dim3(256), 0, st, p);
+}
+
+static hipError_t launch_sweep_mfma(hipStream_t st, const SweepParams& p) {
+    constexpr int NW = 4;
+    dim3 grid((p.nrows + NW * MT_ROWS - 1) / (NW * MT_ROWS), p.ksplit);
+    if (p.ksplit > 1) {
+        hipLaunchKernelGGL((k_sweep_mfma<NW, true>), grid, dim3(NW * 64), 0, st, p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        switch (p.S) {
+#define DR_EP(n) case n: launch_epilogue_s<n>(st, p); break;
+            DR_EP(9) DR_EP(10) DR_EP(11) DR_EP(12) DR_EP(13) DR_EP(14) DR_EP(15) DR_EP(16)
+#undef DR_EP
+            default: return hipErrorInvalidValue;
+        }
+    } else {
+        hipLaunchKernelGGL((k_sweep_mfma<NW, false>), grid, dim3(NW * 64), 0, st, p);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_sweep(hipStream_t st, const SweepParams& p_in) {
     if (p_in.nrows <= 0) return hipSuccess;
     SweepParams p = p_in;
-    static int skew = -1;
+    static int skew = -1, mfma = -1;
     if (skew < 0) { const char* e = getenv("DR_SWEEP_SKEW"); skew = e ? atoi(e) : 37; }
+    if (mfma < 0) { const char* e = getenv("DR_SWEEP_MFMA"); mfma = e ? atoi(e) : 1; }
     p.skew = skew;
+    if (p.S > 8 && mfma) return launch_sweep_mfma(st, p);
     if (p.rpr % 1024 == 0 && p.S == 8) {       // tuning variants (DR_SWEEP_CFG)
         switch (sweep_cfg()) {
             case 1: return launch_cfg<8, 8, 4, 1, false>(st, p);
@@ -252,6 +443,9 @@ hipError_t launch_sweep(hipStream_t st, const SweepParams& p_in) {
             case 6: return launch_cfg<8, 4, 8, 2, true>(st, p);
             case 7: return launch_cfg<8, 4, 16, 1, false>(st, p);
             case 8: return launch_cfg<8, 8, 8, 1, false>(st, p);
+            case 17: return launch_cfg<8, 8, 4, 1, true, 1, 2>(st, p);
+            case 18: return launch_cfg<8, 8, 4, 1, true, 1, 1>(st, p);
+            case 19: return launch_cfg<8, 8, 4, 1, true, 1, 3>(st, p);
             case 9: return launch_cfg<8, 8, 4, 1, false, 3>(st, p);
             case 10: return launch_cfg<8, 8, 4, 1, false, 4>(st, p);
             case 11: return launch_cfg<8, 4, 8, 1, false, 6>(st, p);
@@ -262,6 +456,25 @@ hipError_t launch_sweep(hipStream_t st, const SweepParams& p_in) {
             case 16: return launch_cfg<8, 4, 4, 1, true, 5>(st, p);
             default: break;
         }
+    }
+    if (p.rpr % 1024 == 0 && (p.S == 9 || p.S == 12 || p.S == 16) && sweep_cfg() >= 20) {   // tuning variants
+        const int v = sweep_cfg();
+#define DR_TRY_S(SS) \
+        if (p.S == SS) { \
+            if (v == 21) return launch_cfg<SS, 8, 4, 1, true>(st, p); \
+            if (v == 22) return launch_cfg<SS, 6, 4, 1, true>(st, p); \
+            if (v == 23) return launch_cfg<SS, 4, 8, 1, true>(st, p); \
+            if (v == 24) return launch_cfg<SS, 5, 4, 1, true>(st, p); \
+            if (v == 28) return launch_cfg<SS, 4, 4, 2, true>(st, p); \
+            if (v == 29) return launch_cfg<SS, 4, 4, 4, true>(st, p); \
+            if (v == 30) return launch_cfg<SS, 2, 4, 4, true>(st, p); \
+            if (v == 31) return launch_cfg<SS, 4, 8, 2, true>(st, p); \
+            if (v == 25) return launch_cfg<SS, 8, 4, 1, true, 1, 2>(st, p); \
+            if (v == 26) return launch_cfg<SS, 6, 4, 1, true, 1, 2>(st, p); \
+            if (v == 27) return launch_cfg<SS, 4, 4, 1, true, 1, 2>(st, p); \
+        }
+        DR_TRY_S(9) DR_TRY_S(12) DR_TRY_S(16)
+#undef DR_TRY_S
     }
     switch (p.S) {
 #define DR_CASE(n) case n: return launch_sweep_s<n>(st, p);
