@@ -22,7 +22,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // SPLIT: the columns are cut into gridDim.y ranges (small row shards would otherwise leave most
 // CUs with one block or none); each block then writes its partial sums and k_sweep_epilogue adds
 // them in a fixed order and applies the bin transfer.
-template <int S, int RR, int NW, int CPL, bool NT, int OCC, bool SPLIT, int LOOKAHEAD = 0>
+template <int S, int RR, int NW, int CPL, bool NT, int OCC, bool SPLIT>
 __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
     constexpr int TC = 256 * CPL;
     __shared__ __attribute__((aligned(16))) float sR[2][S][TC];
@@ -106,45 +106,19 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
             load_rtile(tt);
         }
         const int buf = t & 1;
-        if (LOOKAHEAD == 0) {
 #pragma unroll
-            for (int c = 0; c < CPL; c++)
+        for (int c = 0; c < CPL; c++)
 #pragma unroll
-                for (int s = 0; s < S; s++) {
-                    const v4f x = *reinterpret_cast<const v4f*>(&sR[buf][s][c * 256 + lane * 4]);
+            for (int s = 0; s < S; s++) {
+                const v4f x = *reinterpret_cast<const v4f*>(&sR[buf][s][c * 256 + lane * 4]);
 #pragma unroll
-                    for (int r = 0; r < RR; r++) {
-                        acc[r][s] = fmaf(fcur[r][c].x, x.x, acc[r][s]);
-                        acc[r][s] = fmaf(fcur[r][c].y, x.y, acc[r][s]);
-                        acc[r][s] = fmaf(fcur[r][c].z, x.z, acc[r][s]);
-                        acc[r][s] = fmaf(fcur[r][c].w, x.w, acc[r][s]);
-                    }
-                }
-        } else {
-            // residual values are read LOOKAHEAD bins ahead of their use and the scheduler is fenced per bin,
-            // so the compiler cannot hoist all S LDS reads (4 VGPRs each) to the top of the tile
-#pragma unroll
-            for (int c = 0; c < CPL; c++) {
-                v4f xq[LOOKAHEAD + 1];
-#pragma unroll
-                for (int a = 0; a < LOOKAHEAD; a++)
-                    if (a < S) xq[a] = *reinterpret_cast<const v4f*>(&sR[buf][a][c * 256 + lane * 4]);
-#pragma unroll
-                for (int s = 0; s < S; s++) {
-                    if (s + LOOKAHEAD < S)
-                        xq[(s + LOOKAHEAD) % (LOOKAHEAD + 1)] = *reinterpret_cast<const v4f*>(&sR[buf][s + LOOKAHEAD][c * 256 + lane * 4]);
-                    const v4f x = xq[s % (LOOKAHEAD + 1)];
-#pragma unroll
-                    for (int r = 0; r < RR; r++) {
-                        acc[r][s] = fmaf(fcur[r][c].x, x.x, acc[r][s]);
-                        acc[r][s] = fmaf(fcur[r][c].y, x.y, acc[r][s]);
-                        acc[r][s] = fmaf(fcur[r][c].z, x.z, acc[r][s]);
-                        acc[r][s] = fmaf(fcur[r][c].w, x.w, acc[r][s]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int r = 0; r < RR; r++) {
+                    acc[r][s] = fmaf(fcur[r][c].x, x.x, acc[r][s]);
+                    acc[r][s] = fmaf(fcur[r][c].y, x.y, acc[r][s]);
+                    acc[r][s] = fmaf(fcur[r][c].z, x.z, acc[r][s]);
+                    acc[r][s] = fmaf(fcur[r][c].w, x.w, acc[r][s]);
                 }
             }
-        }
         if (more) store_rtile(buf ^ 1);
         __syncthreads();
 #pragma unroll
@@ -355,17 +329,17 @@ __global__ void k_sweep_epilogue(SweepParams P) {
     *b = *b + v;
 }
 
-template <int S, int RR, int NW, int CPL, bool NT, int OCC = 1, int LOOKAHEAD = 0>
+template <int S, int RR, int NW, int CPL, bool NT, int OCC = 1>
 static hipError_t launch_cfg(hipStream_t st, const SweepParams& p) {
     const int rows_per_block = RR * NW;
     dim3 grid((p.nrows + rows_per_block - 1) / rows_per_block, p.ksplit);
     if (p.ksplit > 1) {
-        hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC, true, LOOKAHEAD>), grid, dim3(NW * 64), 0, st, p);
+        hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC, true>), grid, dim3(NW * 64), 0, st, p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_sweep_epilogue<S>), dim3((p.nrows * S + 255) / 256), dim3(256), 0, st, p);
     } else {
-        hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC, false, LOOKAHEAD>), grid, dim3(NW * 64), 0, st, p);
+        hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC, false>), grid, dim3(NW * 64), 0, st, p);
     }
     return hipGetLastError();
 }
@@ -443,38 +417,8 @@ hipError_t launch_sweep(hipStream_t st, const SweepParams& p_in) {
             case 6: return launch_cfg<8, 4, 8, 2, true>(st, p);
             case 7: return launch_cfg<8, 4, 16, 1, false>(st, p);
             case 8: return launch_cfg<8, 8, 8, 1, false>(st, p);
-            case 17: return launch_cfg<8, 8, 4, 1, true, 1, 2>(st, p);
-            case 18: return launch_cfg<8, 8, 4, 1, true, 1, 1>(st, p);
-            case 19: return launch_cfg<8, 8, 4, 1, true, 1, 3>(st, p);
-            case 9: return launch_cfg<8, 8, 4, 1, false, 3>(st, p);
-            case 10: return launch_cfg<8, 8, 4, 1, false, 4>(st, p);
-            case 11: return launch_cfg<8, 4, 8, 1, false, 6>(st, p);
-            case 12: return launch_cfg<8, 4, 4, 1, false, 5>(st, p);
-            case 13: return launch_cfg<8, 4, 4, 2, false, 4>(st, p);
-            case 14: return launch_cfg<8, 4, 8, 1, true, 4>(st, p);
-            case 15: return launch_cfg<8, 2, 8, 2, false, 6>(st, p);
-            case 16: return launch_cfg<8, 4, 4, 1, true, 5>(st, p);
             default: break;
         }
-    }
-    if (p.rpr % 1024 == 0 && (p.S == 9 || p.S == 12 || p.S == 16) && sweep_cfg() >= 20) {   // tuning variants
-        const int v = sweep_cfg();
-#define DR_TRY_S(SS) \
-        if (p.S == SS) { \
-            if (v == 21) return launch_cfg<SS, 8, 4, 1, true>(st, p); \
-            if (v == 22) return launch_cfg<SS, 6, 4, 1, true>(st, p); \
-            if (v == 23) return launch_cfg<SS, 4, 8, 1, true>(st, p); \
-            if (v == 24) return launch_cfg<SS, 5, 4, 1, true>(st, p); \
-            if (v == 28) return launch_cfg<SS, 4, 4, 2, true>(st, p); \
-            if (v == 29) return launch_cfg<SS, 4, 4, 4, true>(st, p); \
-            if (v == 30) return launch_cfg<SS, 2, 4, 4, true>(st, p); \
-            if (v == 31) return launch_cfg<SS, 4, 8, 2, true>(st, p); \
-            if (v == 25) return launch_cfg<SS, 8, 4, 1, true, 1, 2>(st, p); \
-            if (v == 26) return launch_cfg<SS, 6, 4, 1, true, 1, 2>(st, p); \
-            if (v == 27) return launch_cfg<SS, 4, 4, 1, true, 1, 2>(st, p); \
-        }
-        DR_TRY_S(9) DR_TRY_S(12) DR_TRY_S(16)
-#undef DR_TRY_S
     }
     switch (p.S) {
 #define DR_CASE(n) case n: return launch_sweep_s<n>(st, p);
