@@ -68,6 +68,7 @@ struct dr_context {
     int* d_mat = nullptr;
     double* d_sums = nullptr;
     float* d_Gpart = nullptr;
+    float* d_stage = nullptr;     // N x S staging for layout conversion on read-back
     int ksplit = 1;
     int cur = 0;
     bool have_solver = false;
@@ -91,7 +92,7 @@ void free_F(dr_context* c) {
 }
 void free_solver(dr_context* c) {
     hipFree(c->d_M); hipFree(c->d_E); hipFree(c->d_B); hipFree(c->d_R[0]); hipFree(c->d_R[1]);
-    hipFree(c->d_mat); hipFree(c->d_sums); hipFree(c->d_Gpart); c->d_Gpart = nullptr;
+    hipFree(c->d_mat); hipFree(c->d_sums); hipFree(c->d_Gpart); c->d_Gpart = nullptr; hipFree(c->d_stage); c->d_stage = nullptr;
     c->d_M = c->d_E = c->d_B = c->d_R[0] = c->d_R[1] = nullptr; c->d_mat = nullptr; c->d_sums = nullptr;
     c->have_solver = false;
 }
@@ -437,8 +438,8 @@ int dr_solver_init(dr_context* c, int S, const float* E, const float* M, int n_m
     HIPCHK(hipMalloc(&c->d_sums, sizeof(double) * DR_MAX_BINS));
     c->ksplit = sweep_ksplit(c->nrows, S, (int)c->ldF);
     if (c->ksplit > 1) HIPCHK(hipMalloc(&c->d_Gpart, sizeof(float) * (size_t)c->ksplit * std::max(c->nrows, 1) * S));
-    float* tmp = nullptr;
-    HIPCHK(hipMalloc(&tmp, sizeof(float) * (size_t)c->N * S));
+    HIPCHK(hipMalloc(&c->d_stage, sizeof(float) * (size_t)c->N * S));
+    float* tmp = c->d_stage;
     HIPCHK(hipMemcpyAsync(tmp, E, sizeof(float) * (size_t)c->N * S, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->d_E, 0, sizeof(float) * full, c->stream));
     HIPCHK(hipMemsetAsync(c->d_R[0], 0, sizeof(float) * full, c->stream));
@@ -449,7 +450,6 @@ int dr_solver_init(dr_context* c, int S, const float* E, const float* M, int n_m
     if (c->nrows > 0)
         HIPCHK(hipMemcpyAsync(c->d_mat, mat_of_patch + c->row0, sizeof(int) * (size_t)c->nrows, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    hipFree(tmp);
     c->have_solver = true;
     return dr_solver_reset(c);
 }
@@ -518,8 +518,7 @@ int dr_solver_converge(dr_context* c, float threshold, int per_bin, int max_iter
 int dr_solver_read(dr_context* c, float* B, float* R) {
     CTX(c);
     if (!c->have_solver) return fail(DR_ERR_STATE, "dr_solver_init has not been called");
-    float* tmp = nullptr;
-    HIPCHK(hipMalloc(&tmp, sizeof(float) * (size_t)c->N * c->S));
+    float* tmp = c->d_stage;
     if (R) {
         HIPCHK(launch_gather_rows(c->stream, c->d_R[c->cur], c->N, c->S, c->rpr, c->world, tmp));
         HIPCHK(hipMemcpyAsync(R, tmp, sizeof(float) * (size_t)c->N * c->S, hipMemcpyDeviceToHost, c->stream));
@@ -530,7 +529,6 @@ int dr_solver_read(dr_context* c, float* B, float* R) {
         HIPCHK(hipMemcpyAsync(B + (size_t)c->row0 * c->S, tmp, sizeof(float) * (size_t)c->nrows * c->S, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
-    hipFree(tmp);
     return DR_OK;
 }
 

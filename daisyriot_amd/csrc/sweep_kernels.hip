@@ -33,8 +33,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rbase = (blockIdx.x * NW + wave) * RR;       // first local row of this wave (uniform)
     const int ntiles_all = (P.world * P.rpr) / TC;
-    const int ntiles = SPLIT ? ntiles_all / (int)gridDim.y : ntiles_all;      // tiles of this block
-    const int tile0 = SPLIT ? (int)blockIdx.y * ntiles : 0;
+    // tiles of this block: the column ranges need not be equal, they only have to cover every tile once
+    const int tile0 = SPLIT ? (int)(((long long)blockIdx.y * ntiles_all) / (int)gridDim.y) : 0;
+    const int ntiles = SPLIT ? (int)(((long long)(blockIdx.y + 1) * ntiles_all) / (int)gridDim.y) - tile0 : ntiles_all;
     const int tiles_per_chunk = P.rpr / TC;
 
     // wave-uniform row bases (SGPRs); rows past the shard are clamped for loading, masked at the end
@@ -197,8 +198,8 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_mfma(SweepParams P) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rbase = (blockIdx.x * NW + wave) * MT_ROWS;
     const int ntiles_all = (P.world * P.rpr) / MT_TC;
-    const int ntiles = SPLIT ? ntiles_all / (int)gridDim.y : ntiles_all;
-    const int tile0 = SPLIT ? (int)blockIdx.y * ntiles : 0;
+    const int tile0 = SPLIT ? (int)(((long long)blockIdx.y * ntiles_all) / (int)gridDim.y) : 0;
+    const int ntiles = SPLIT ? (int)(((long long)(blockIdx.y + 1) * ntiles_all) / (int)gridDim.y) - tile0 : ntiles_all;
     const int tiles_per_chunk = P.rpr / MT_TC;
 
     // bins S..15 of the residual tile are zero and never rewritten
@@ -346,7 +347,7 @@ static hipError_t launch_cfg(hipStream_t st, const SweepParams& p) {
 
 // How many column ranges to cut the sweep into.  With 512 or more row blocks (2 per CU) the fused
 // single pass is fastest; below that, cut columns until there are about 1024 blocks, each block
-// keeping at least 16 tiles; the count must divide the tile count.  Measured at N = 65 536 on one
+// keeping at least 8 tiles (the ranges need not be equal).  Measured at N = 65 536 on one
 // MI355X (profiles/r01/sweep_shards.md): 8192 rows 0.437 ms unsplit -> 0.342 ms with 4 ranges.
 int sweep_ksplit(int nrows, int S, int total_cols) {
     const int rows_per_block = (S <= 8) ? 32 : 4 * MT_ROWS;      // k_sweep: 4 waves x 8 rows; k_sweep_mfma: 4 x 16
@@ -357,7 +358,7 @@ int sweep_ksplit(int nrows, int S, int total_cols) {
     int want = forced > 0 ? forced : (row_blocks >= 512 ? 1 : (1024 + row_blocks - 1) / (row_blocks > 0 ? row_blocks : 1));
     int ks = 1;
     for (int k = 1; k <= want && k <= 64; k++)
-        if (ntiles % k == 0 && ntiles / k >= (forced > 0 ? 1 : 16)) ks = k;
+        if (ntiles / k >= (forced > 0 ? 1 : 8)) ks = k;       // every range keeps at least 8 tiles
     return ks;
 }
 
