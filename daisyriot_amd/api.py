@@ -17,6 +17,7 @@ RULE_RECIPROCITY = 1     # ini cuda_on = false (vs/OptixPrimeFunctionality.cpp:3
 RAYS_PER_PATCH = 50      # vs/Defines.h:25
 ORIGIN_EPS = 1e-6        # vs/OptixPrimeFunctionality.cpp:194
 MAX_BINS = 16
+DISPLAY_BW, DISPLAY_RGB, DISPLAY_SPECTRAL = 0, 1, 2   # vs/Lightning.h:406-408, 332-334, 168-183
 
 EXPORTS = [
     "dr_last_error", "dr_context_create", "dr_context_destroy", "dr_set_stream", "dr_set_shard",
@@ -26,6 +27,7 @@ EXPORTS = [
     "dr_comm_unique_id", "dr_comm_init", "dr_get_info", "dr_profile_enable", "dr_profile_reset",
     "dr_synchronize", "dr_debug_read_bvh", "dr_shard_rows", "dr_residual_offset",
     "dr_comm_manual", "dr_exchange_export", "dr_exchange_import", "dr_debug_read_array",
+    "dr_display_patch_colors", "dr_display_vertex_colors",
 ]
 
 
@@ -86,6 +88,8 @@ def load_library(path=None):
     L.dr_exchange_import.argtypes = [vp, i, vp]
     L.dr_shard_rows.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.dr_residual_offset.argtypes = [i, i, i, i]
+    L.dr_display_patch_colors.argtypes = [vp, i, vp, vp]
+    L.dr_display_vertex_colors.argtypes = [vp, vp, vp, vp, i, vp]
     for name in EXPORTS:
         if name not in ("dr_last_error", "dr_residual_offset"):
             getattr(L, name).restype = i
@@ -265,6 +269,32 @@ class Context:
         s = np.zeros(MAX_BINS, np.float64)
         self._chk(self.L.dr_solver_residual_sums(self.h, _p(s)), "dr_solver_residual_sums")
         return s[:self.S].copy()
+
+    # -- display colours
+    def patch_colors(self, mode, xyz_per_bin=None):
+        """Display colours of this rank's rows, (nrows, 3): DISPLAY_BW / DISPLAY_RGB / DISPLAY_SPECTRAL."""
+        nrows = self.info().nrows
+        out = np.zeros((nrows, 3), np.float32)
+        xyz = _f32(xyz_per_bin) if xyz_per_bin is not None else None
+        if xyz is not None and xyz.shape != (self.S, 3):
+            raise DaisyRiotError("xyz_per_bin must be (S, 3)")
+        self._chk(self.L.dr_display_patch_colors(self.h, int(mode), _p(xyz) if xyz is not None else None, _p(out)),
+                  "dr_display_patch_colors")
+        return out
+
+    def vertex_colors(self, vtx_off, vtx_tri, rgb_all=None):
+        """Mean colour of the patches around every vertex (CSR adjacency), (V, 3)."""
+        off, adj = _i32(vtx_off), _i32(vtx_tri)
+        V = off.shape[0] - 1
+        out = np.zeros((V, 3), np.float32)
+        rgb = _f32(rgb_all) if rgb_all is not None else None
+        if rgb is not None and rgb.shape != (self.N, 3):
+            raise DaisyRiotError("rgb_all must be (N, 3)")
+        if adj.size == 0:
+            adj = np.zeros(1, np.int32)
+        self._chk(self.L.dr_display_vertex_colors(self.h, _p(rgb) if rgb is not None else None, _p(off), _p(adj), V, _p(out)),
+                  "dr_display_vertex_colors")
+        return out
 
     # -- measurement
     def info(self):

@@ -69,6 +69,8 @@ struct dr_context {
     double* d_sums = nullptr;
     float* d_Gpart = nullptr;
     float* d_stage = nullptr;     // N x S staging for layout conversion on read-back
+    float* d_rgb = nullptr;       // display colours of the local rows (nrows x 3), valid after dr_display_patch_colors
+    bool have_rgb = false;
     int ksplit = 1;
     int cur = 0;
     bool have_solver = false;
@@ -93,6 +95,7 @@ void free_F(dr_context* c) {
 void free_solver(dr_context* c) {
     hipFree(c->d_M); hipFree(c->d_E); hipFree(c->d_B); hipFree(c->d_R[0]); hipFree(c->d_R[1]);
     hipFree(c->d_mat); hipFree(c->d_sums); hipFree(c->d_Gpart); c->d_Gpart = nullptr; hipFree(c->d_stage); c->d_stage = nullptr;
+    hipFree(c->d_rgb); c->d_rgb = nullptr; c->have_rgb = false;
     c->d_M = c->d_E = c->d_B = c->d_R[0] = c->d_R[1] = nullptr; c->d_mat = nullptr; c->d_sums = nullptr;
     c->have_solver = false;
 }
@@ -438,7 +441,7 @@ int dr_solver_init(dr_context* c, int S, const float* E, const float* M, int n_m
     HIPCHK(hipMalloc(&c->d_sums, sizeof(double) * DR_MAX_BINS));
     c->ksplit = sweep_ksplit(c->nrows, S, (int)c->ldF);
     if (c->ksplit > 1) HIPCHK(hipMalloc(&c->d_Gpart, sizeof(float) * (size_t)c->ksplit * std::max(c->nrows, 1) * S));
-    HIPCHK(hipMalloc(&c->d_stage, sizeof(float) * (size_t)c->N * S));
+    HIPCHK(hipMalloc(&c->d_stage, sizeof(float) * std::max((size_t)c->N * S, (size_t)3 * DR_MAX_BINS)));
     float* tmp = c->d_stage;
     HIPCHK(hipMemcpyAsync(tmp, E, sizeof(float) * (size_t)c->N * S, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->d_E, 0, sizeof(float) * full, c->stream));
@@ -529,6 +532,56 @@ int dr_solver_read(dr_context* c, float* B, float* R) {
         HIPCHK(hipMemcpyAsync(B + (size_t)c->row0 * c->S, tmp, sizeof(float) * (size_t)c->nrows * c->S, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
+    return DR_OK;
+}
+
+int dr_display_patch_colors(dr_context* c, int mode, const float* xyz, float* rgb) {
+    CTX(c);
+    if (!c->have_solver) return fail(DR_ERR_STATE, "dr_solver_init has not been called");
+    if (mode < DR_DISPLAY_BW || mode > DR_DISPLAY_SPECTRAL) return fail(DR_ERR_INVALID, "display mode %d", mode);
+    if (mode == DR_DISPLAY_RGB && c->S != 3) return fail(DR_ERR_INVALID, "RGB display needs 3 bins, the solver has %d", c->S);
+    if (mode == DR_DISPLAY_BW && c->S != 1) return fail(DR_ERR_INVALID, "BW display needs 1 bin, the solver has %d", c->S);
+    if (mode == DR_DISPLAY_SPECTRAL && !xyz) return fail(DR_ERR_INVALID, "xyz_per_bin is null");
+    if (!c->d_rgb) HIPCHK(hipMalloc(&c->d_rgb, sizeof(float) * 3 * (size_t)std::max(c->nrows, 1)));
+    float* d_xyz = c->d_stage;      // S*3 floats of the (N*S) staging buffer
+    if (mode == DR_DISPLAY_SPECTRAL)
+        HIPCHK(hipMemcpyAsync(d_xyz, xyz, sizeof(float) * 3 * (size_t)c->S, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_patch_colors(c->stream, c->d_B, c->nrows, c->rpr, c->S, mode, d_xyz, c->d_rgb));
+    if (rgb && c->nrows > 0)
+        HIPCHK(hipMemcpyAsync(rgb, c->d_rgb, sizeof(float) * 3 * (size_t)c->nrows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_rgb = true;
+    return DR_OK;
+}
+
+int dr_display_vertex_colors(dr_context* c, const float* rgb_all, const int32_t* vtx_off, const int32_t* vtx_tri, int V,
+                             float* out) {
+    CTX(c);
+    if (c->N <= 0) return fail(DR_ERR_STATE, "no mesh set");
+    if (!vtx_off || !vtx_tri || !out || V < 1) return fail(DR_ERR_INVALID, "null adjacency/output or V < 1");
+    if (!rgb_all && (c->world != 1 || !c->have_rgb))
+        return fail(DR_ERR_STATE, "rgb_all is null and no device colours of all patches exist (world %d)", c->world);
+    if (vtx_off[0] != 0) return fail(DR_ERR_INVALID, "vtx_off[0] must be 0");
+    for (int v = 0; v < V; v++)
+        if (vtx_off[v + 1] < vtx_off[v]) return fail(DR_ERR_INVALID, "vtx_off decreases at vertex %d", v);
+    const int n_adj = vtx_off[V];
+    for (int k = 0; k < n_adj; k++)
+        if (vtx_tri[k] < 0 || vtx_tri[k] >= c->N) return fail(DR_ERR_INVALID, "vtx_tri[%d] = %d out of range", k, vtx_tri[k]);
+    int *d_off = nullptr, *d_adj = nullptr;
+    float *d_out = nullptr, *d_in = nullptr;
+    auto cleanup = [&]() { hipFree(d_off); hipFree(d_adj); hipFree(d_out); hipFree(d_in); };
+    hipError_t e = hipMalloc(&d_off, sizeof(int) * ((size_t)V + 1));
+    if (e == hipSuccess) e = hipMalloc(&d_adj, sizeof(int) * (size_t)std::max(n_adj, 1));
+    if (e == hipSuccess) e = hipMalloc(&d_out, sizeof(float) * 3 * (size_t)V);
+    if (e == hipSuccess && rgb_all) e = hipMalloc(&d_in, sizeof(float) * 3 * (size_t)c->N);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, vtx_off, sizeof(int) * ((size_t)V + 1), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && n_adj > 0) e = hipMemcpyAsync(d_adj, vtx_tri, sizeof(int) * (size_t)n_adj, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && rgb_all) e = hipMemcpyAsync(d_in, rgb_all, sizeof(float) * 3 * (size_t)c->N, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_vertex_colors(c->stream, rgb_all ? d_in : c->d_rgb, V, d_off, d_adj, d_out);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(float) * 3 * (size_t)V, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? DR_ERR_NOMEM : DR_ERR_DEVICE, "vertex colours: %s", hipGetErrorString(e));
     return DR_OK;
 }
 

@@ -87,6 +87,9 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float scen
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p);
 hipError_t launch_sweep(hipStream_t st, const SweepParams& p);
 int sweep_ksplit(int nrows, int S, int total_cols);
+hipError_t launch_patch_colors(hipStream_t st, const float* B, int nrows, int rpr, int S, int mode, const float* xyz,
+                               float* rgb);
+hipError_t launch_vertex_colors(hipStream_t st, const float* rgb, int V, const int* off, const int* adj, float* out);
 hipError_t launch_colsums(hipStream_t st, const float* R, int world, int S, int rpr, double* sums);
 // layout conversion between the ABI's patch-major N x S and the device's bin-major chunks
 hipError_t launch_scatter_rows(hipStream_t st, const float* src_NxS, int N, int S, int rpr, int world,

@@ -83,13 +83,11 @@ int main(int argc, char** argv) {
             f << "ply\nformat ascii 1.0\nelement vertex " << mesh.vertices.size()
               << "\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n"
               << "element face " << mesh.numtriangles << "\nproperty list uchar int vertex_indices\nend_header\n";
+            const std::vector<vec3> vc = lightning->vertex_colors();
             for (size_t v = 0; v < mesh.vertices.size(); v++) {
-                vec3 c{ 0, 0, 0 };
-                for (int t : mesh.trianglesPerVertex[v]) { vec3 p = lightning->get_color_of_patch(t); c.x += p.x; c.y += p.y; c.z += p.z; }
-                float n = (float)std::max<size_t>(1, mesh.trianglesPerVertex[v].size());
-                auto to8 = [](float x) { x = x < 0 ? 0 : (x > 1 ? 1 : x); return (int)(x * 255.0f + 0.5f); };
+                auto to8 = [](float x) { x = x > 0 ? (x > 1 ? 1 : x) : 0; return (int)(x * 255.0f + 0.5f); };
                 f << mesh.vertices[v].x << " " << mesh.vertices[v].y << " " << mesh.vertices[v].z << " "
-                  << to8(c.x / n) << " " << to8(c.y / n) << " " << to8(c.z / n) << "\n";
+                  << to8(vc[v].x) << " " << to8(vc[v].y) << " " << to8(vc[v].z) << "\n";
             }
             for (int t = 0; t < mesh.numtriangles; t++)
                 f << "3 " << mesh.triangleIndices[(size_t)t].vertex.x << " " << mesh.triangleIndices[(size_t)t].vertex.y << " "

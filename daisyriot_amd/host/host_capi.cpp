@@ -61,6 +61,8 @@ long drh_ini_integer(drh_ini* h, const char* sec, const char* name, long def) { 
 double drh_ini_real(drh_ini* h, const char* sec, const char* name, double def) { return h->r.GetReal(sec, name, def); }
 int drh_ini_boolean(drh_ini* h, const char* sec, const char* name, int def) { return h->r.GetBoolean(sec, name, def != 0) ? 1 : 0; }
 
+void drh_xyz_fit(double wavelength, float* out3) { vec3 v = cie1931_xyz_fit(wavelength); out3[0] = v.x; out3[1] = v.y; out3[2] = v.z; }
+
 void drh_visibility_samples(int K, unsigned seed, float* uv) {
     std::vector<UV> r = make_visibility_samples(K, seed);
     std::memcpy(uv, r.data(), sizeof(UV) * (size_t)K);

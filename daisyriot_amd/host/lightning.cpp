@@ -20,24 +20,20 @@ std::vector<UV> make_visibility_samples(int K, unsigned seed) {
     return r;
 }
 
-namespace {
-
-void chk(int rc, const char* what) {
-    if (rc != DR_OK) throw HipError(std::string(what) + ": " + dr_last_error());
-}
-
-// CIE 1931 colour-matching fit of Wyman, Sloan, Shirley (JCGT 2013), as color.h:14-45 uses it
-vec3 cie_xyz(double w) {
+// CIE 1931 colour-matching fit of Wyman, Sloan, Shirley (JCGT 2013), the table SpectralLightning fills per
+// wavelength (color.h:14-45, Lightning.h:128-131): evaluated in double, stored as float
+vec3 cie1931_xyz_fit(double w) {
     auto g = [](double x, double mu, double s1, double s2) { double t = (x - mu) * (x < mu ? s1 : s2); return std::exp(-0.5 * t * t); };
     double x = 0.362 * g(w, 442.0, 0.0624, 0.0374) + 1.056 * g(w, 599.8, 0.0264, 0.0323) - 0.065 * g(w, 501.1, 0.0490, 0.0382);
     double y = 0.821 * g(w, 568.8, 0.0213, 0.0247) + 0.286 * g(w, 530.9, 0.0613, 0.0322);
     double z = 1.217 * g(w, 437.0, 0.0845, 0.0278) + 0.681 * g(w, 459.0, 0.0385, 0.0725);
     return vec3{ (float)x, (float)y, (float)z };
 }
-vec3 xyz_to_rgb(const vec3& c) {        // color.h:48-52
-    return vec3{ 3.240479f * c.x - 1.537150f * c.y - 0.498535f * c.z,
-                 -0.969256f * c.x + 1.875991f * c.y + 0.041556f * c.z,
-                 0.055648f * c.x - 0.204043f * c.y + 1.057311f * c.z };
+
+namespace {
+
+void chk(int rc, const char* what) {
+    if (rc != DR_OK) throw HipError(std::string(what) + ": " + dr_last_error());
 }
 
 // Reader/writer of the reference's F cache (Lightning.h:21-74): ints rows, cols, nnz, outerSize, innerSize,
@@ -103,7 +99,7 @@ public:
                     if (e > 0.0f) E[(size_t)j * S_ + s] = e * emission_value;
                 }
             for (const Material& m : mesh.materials) M.insert(M.end(), m.M.begin(), m.M.end());
-            for (float w : wavelengths) xyz_.push_back(cie_xyz(w));
+            for (float w : wavelengths) xyz_.push_back(cie1931_xyz_fit(w));
         } else if (method == 1) {                // RGBLightning (Lightning.h:317-382)
             S_ = 3;
             threshold_ = 0.0001f; per_bin_ = true;            // Lightning.h:337
@@ -160,16 +156,20 @@ public:
     }
     ~LightningHIP() override { dr_context_destroy(ctx_); }
 
-    vec3 get_color_of_patch(int i) override {
-        const float* b = &B_[(size_t)i * S_];
-        if (method_ == 1) return vec3{ b[0], b[1], b[2] };                   // Lightning.h:332-334
-        if (method_ == 0) return vec3{ b[0], b[0], b[0] };                   // Lightning.h:406-408
-        vec3 xyz{ 0, 0, 0 };                                                 // Lightning.h:168-183
-        for (int s = 0; s < S_; s++) { xyz.x += xyz_[(size_t)s].x * b[s]; xyz.y += xyz_[(size_t)s].y * b[s]; xyz.z += xyz_[(size_t)s].z * b[s]; }
-        vec3 rgb = xyz_to_rgb(xyz);
-        float mx = std::fmax(rgb.x, std::fmax(rgb.y, rgb.z));
-        if (mx > 1) rgb = vec3{ rgb.x / mx, rgb.y / mx, rgb.z / mx };
-        return rgb;
+    // rgb_color_cache of the reference (Lightning.h:168-183, 332-334, 406-408), filled on the device
+    vec3 get_color_of_patch(int i) override { return rgb_[(size_t)i]; }
+    std::vector<vec3> vertex_colors() override {
+        const size_t V = mesh_.vertices.size();
+        std::vector<int32_t> off(V + 1, 0), adj;
+        for (size_t v = 0; v < V; v++) {
+            const std::vector<int>& t = mesh_.trianglesPerVertex[v];
+            adj.insert(adj.end(), t.begin(), t.end());
+            off[v + 1] = (int32_t)adj.size();
+        }
+        if (adj.empty()) adj.push_back(0);
+        std::vector<vec3> out(V);
+        chk(dr_display_vertex_colors(ctx_, nullptr, off.data(), adj.data(), (int)V, &out[0].x), "dr_display_vertex_colors");
+        return out;
     }
     void converge_lightning() override {
         int it = 0;
@@ -194,14 +194,19 @@ public:
     dr_info info() override { dr_info i; chk(dr_get_info(ctx_, &i), "dr_get_info"); return i; }
 
 private:
-    void refresh() { chk(dr_solver_read(ctx_, B_.data(), nullptr), "dr_solver_read"); }
+    void refresh() {
+        chk(dr_solver_read(ctx_, B_.data(), nullptr), "dr_solver_read");
+        rgb_.resize((size_t)N_);
+        const int mode = method_ == 2 ? DR_DISPLAY_SPECTRAL : (method_ == 1 ? DR_DISPLAY_RGB : DR_DISPLAY_BW);
+        chk(dr_display_patch_colors(ctx_, mode, method_ == 2 ? &xyz_[0].x : nullptr, &rgb_[0].x), "dr_display_patch_colors");
+    }
     int method_, max_passes_, N_ = 0, S_ = 0, numpasses_ = 0;
     float threshold_ = 0;
     bool per_bin_ = false;
     MeshS& mesh_;
     dr_context* ctx_ = nullptr;
     std::vector<float> B_;
-    std::vector<vec3> xyz_;
+    std::vector<vec3> xyz_, rgb_;
 };
 
 }  // namespace

@@ -18,6 +18,9 @@ struct UV { float u, v; };              // visual studio/Defines.h:3-6
 // from std::mt19937(seed) instead of srand(time()) so runs are reproducible
 std::vector<UV> make_visibility_samples(int K = DR_RAYS_PER_PATCH, unsigned seed = 20191);
 
+// xyz_per_wavelength entry of SpectralLightning (color.h:14-45)
+vec3 cie1931_xyz_fit(double wavelength);
+
 struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
 
 class Lightning {
@@ -39,6 +42,8 @@ public:
     virtual const std::vector<float>& lightningvalues() const = 0;   // N x S patch-major
     virtual int bins() const = 0;
     virtual dr_info info() = 0;
+    // per-vertex display colour = mean over MeshS::trianglesPerVertex (Drawer.cpp:161-186), on the device
+    virtual std::vector<vec3> vertex_colors() = 0;
 };
 
 }  // namespace daisy

@@ -39,6 +39,18 @@ class Scene:
         return np.where(self.emit[self.mat_of_patch] > 0, e, 0).astype(np.float32)
 
 
+def vertex_adjacency(tri_v, V):
+    """MeshS::trianglesPerVertex (vs/MeshS.cpp:113-115) as CSR (offsets V+1, triangle ids): per vertex the
+    triangles that use it, in load order -- the lists Drawer::interpolate averages over."""
+    tri_v = np.asarray(tri_v)
+    flat_v = tri_v.reshape(-1)
+    flat_t = np.repeat(np.arange(tri_v.shape[0], dtype=np.int32), 3)
+    order = np.argsort(flat_v, kind="stable")               # stable: load order inside each vertex's list
+    off = np.zeros(V + 1, np.int32)
+    off[1:] = np.cumsum(np.bincount(flat_v, minlength=V))
+    return off, flat_t[order].astype(np.int32)
+
+
 def visibility_samples(K=50, seed=20191):
     """K (u,v) pairs by the reference's formula (vs/OptixPrimeFunctionality.cpp:57-62:
     v *= 1-u) from mt19937(seed); the same K samples serve every pair."""

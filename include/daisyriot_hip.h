@@ -134,6 +134,22 @@ int dr_solver_reset(dr_context* ctx);
 int dr_solver_read(dr_context* ctx, float* B, float* R);
 int dr_solver_residual_sums(dr_context* ctx, double* sums /* S */);
 
+/* ---- display colours (what the viewer shows; computed from the resident B) ---- */
+#define DR_DISPLAY_BW       0   /* BWLightning::get_color_of_patch   (vs/Lightning.h:406-408): (B,B,B)        */
+#define DR_DISPLAY_RGB      1   /* RGBLightning::get_color_of_patch  (vs/Lightning.h:332-334): (B0,B1,B2)     */
+#define DR_DISPLAY_SPECTRAL 2   /* SpectralLightning::update_color_cache (vs/Lightning.h:168-183): XYZ fit ->
+                                 * XYZToRGB (vs/color.h:48-52) -> divided by max(r,g,b) when that is > 1       */
+/* Colours of this rank's rows into rgb (rows_of_this_rank*3, nullable: the colours also stay on
+ * the device for dr_display_vertex_colors).  xyz_per_bin = S*3 floats, the caller's
+ * xyz_per_wavelength (vs/Lightning.h:128-131); only read in spectral mode. */
+int dr_display_patch_colors(dr_context* ctx, int mode, const float* xyz_per_bin, float* rgb);
+/* Drawer::interpolate's corner values (vs/Drawer.cpp:161-186): per vertex the mean colour of the
+ * patches around it, summed in the order given, over MeshS::trianglesPerVertex handed over as
+ * CSR (vtx_off V+1 offsets into vtx_tri).  rgb_all = colours of all N patches (N*3), or NULL to
+ * use what the last dr_display_patch_colors left on the device (single-rank contexts only). */
+int dr_display_vertex_colors(dr_context* ctx, const float* rgb_all, const int32_t* vtx_off,
+                             const int32_t* vtx_tri, int V, float* out /* V*3 */);
+
 /* ---- multi-GPU exchange (no reference counterpart: the reference is single-GPU) ---- */
 /* 128-byte RCCL unique id made on rank 0 and handed to every rank by the host. */
 int dr_comm_unique_id(void* out128);

@@ -55,6 +55,9 @@ def lib():
             f.argtypes = [C.POINTER(_Mesh), fp, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, fp, u8p, C.c_int]
         L.orc_sweep_rows.argtypes = [C.c_int, C.c_int, fp, C.c_long, C.c_int, C.c_int, fp, ip, fp, fp, fp, C.c_int]
         L.orc_residual_sums.argtypes = [C.c_int, C.c_int, fp, fp]
+        L.orc_xyz_fit.argtypes = [C.c_double, fp]
+        L.orc_patch_colors.argtypes = [C.c_int, C.c_int, fp, C.c_int, fp, fp]
+        L.orc_vertex_colors.argtypes = [C.c_int, ip, ip, fp, fp]
         L.orc_converge.restype = C.c_int
         L.orc_converge.argtypes = [C.c_int, C.c_int, fp, fp, ip, fp, fp, C.c_float, C.c_int, C.c_int, C.c_int]
         L.orc_num_threads.restype = C.c_int
@@ -181,6 +184,35 @@ def converge(F, M, mat, E, threshold, per_bin, max_iters, threads=0):
     return it, R, B
 
 
+def xyz_fit(wavelengths):
+    """(S, 3) CIE 1931 fit values the spectral display uses (vs/color.h:14-45)."""
+    out = np.empty((len(wavelengths), 3), np.float32)
+    for k, w in enumerate(wavelengths):
+        o = np.empty(3, np.float32)
+        lib().orc_xyz_fit(C.c_double(float(w)), _p(o))
+        out[k] = o
+    return out
+
+
+def patch_colors(B, mode, xyz=None):
+    B = _f32(B)
+    N, S = B.shape
+    rgb = np.empty((N, 3), np.float32)
+    xyz = _f32(xyz) if xyz is not None else np.zeros((S, 3), np.float32)
+    lib().orc_patch_colors(N, S, _p(B), int(mode), _p(xyz), _p(rgb))
+    return rgb
+
+
+def vertex_colors(vtx_off, vtx_tri, rgb):
+    off, adj, rgb = _i32(vtx_off), _i32(vtx_tri), _f32(rgb)
+    V = off.shape[0] - 1
+    out = np.empty((V, 3), np.float32)
+    if adj.size == 0:
+        adj = np.zeros(1, np.int32)
+    lib().orc_vertex_colors(V, _p(off), _p(adj), _p(rgb), _p(out))
+    return out
+
+
 def num_threads():
     return lib().orc_num_threads()
 
@@ -206,6 +238,9 @@ def ref():
         R.ref_light_pass.argtypes = [C.c_int, C.c_int, fp, fp, ip, fp, fp, C.c_int]
         R.ref_sum.restype = C.c_float
         R.ref_sum.argtypes = [C.c_int, fp]
+        R.ref_xyz_fit.argtypes = [C.c_double, fp]
+        R.ref_patch_color_spectral.argtypes = [C.c_int, fp, fp, fp]
+        R.ref_vertex_color.argtypes = [C.c_int, ip, fp, fp]
         _ref = R
     return _ref
 
@@ -236,3 +271,38 @@ def ref_light_pass(F, M, mat, R, B, mode):
 def ref_sum(x):
     x = _f32(x)
     return float(ref().ref_sum(x.size, _p(x)))
+
+
+def ref_xyz_fit(wavelengths):
+    out = np.empty((len(wavelengths), 3), np.float32)
+    for k, w in enumerate(wavelengths):
+        o = np.empty(3, np.float32)
+        ref().ref_xyz_fit(C.c_double(float(w)), _p(o))
+        out[k] = o
+    return out
+
+
+def ref_patch_colors_spectral(B, xyz):
+    B, xyz = _f32(B), _f32(xyz)
+    out = np.empty((B.shape[0], 3), np.float32)
+    for i in range(B.shape[0]):
+        o = np.empty(3, np.float32)
+        b = np.ascontiguousarray(B[i])
+        ref().ref_patch_color_spectral(B.shape[1], _p(xyz), _p(b), _p(o))
+        out[i] = o
+    return out
+
+
+def ref_vertex_colors(vtx_off, vtx_tri, rgb):
+    off, adj, rgb = _i32(vtx_off), _i32(vtx_tri), _f32(rgb)
+    V = off.shape[0] - 1
+    out = np.zeros((V, 3), np.float32)
+    for v in range(V):
+        n = int(off[v + 1] - off[v])
+        if n == 0:
+            continue
+        a = np.ascontiguousarray(adj[off[v]:off[v + 1]])
+        o = np.empty(3, np.float32)
+        ref().ref_vertex_color(n, _p(a), _p(rgb), _p(o))
+        out[v] = o
+    return out

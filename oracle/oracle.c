@@ -543,6 +543,59 @@ int orc_converge(int N, int S, const float* F, const float* M, const int32_t* ma
     return it;
 }
 
+/* ---- display colour ---------------------------------------------------------- */
+/* daisy_color::cie1931WavelengthToXYZFit, vs/color.h:14-45 (Wyman, Sloan, Shirley 2013): evaluated
+ * in double, truncated to float on return */
+static double lobe(double w, double mu, double s_lo, double s_hi) {
+    double t = (w - mu) * ((w < mu) ? s_lo : s_hi);
+    return exp(-0.5 * t * t);
+}
+void orc_xyz_fit(double w, float out[3]) {
+    double x = 0.362 * lobe(w, 442.0, 0.0624, 0.0374) + 1.056 * lobe(w, 599.8, 0.0264, 0.0323)
+             - 0.065 * lobe(w, 501.1, 0.0490, 0.0382);
+    double y = 0.821 * lobe(w, 568.8, 0.0213, 0.0247) + 0.286 * lobe(w, 530.9, 0.0613, 0.0322);
+    double z = 1.217 * lobe(w, 437.0, 0.0845, 0.0278) + 0.681 * lobe(w, 459.0, 0.0385, 0.0725);
+    out[0] = (float)x; out[1] = (float)y; out[2] = (float)z;
+}
+
+/* mode 0: BWLightning::get_color_of_patch (vs/Lightning.h:406-408); 1: RGBLightning (:332-334);
+ * 2: SpectralLightning::update_color_cache (:168-183) with XYZToRGB (vs/color.h:48-52).
+ * B: N x S patch-major; rgb: N x 3. */
+void orc_patch_colors(int N, int S, const float* B, int mode, const float* xyz, float* rgb) {
+    for (long i = 0; i < N; i++) {
+        const float* b = B + i * S;
+        float r, g, bl;
+        if (mode == 0) { r = g = bl = b[0]; }
+        else if (mode == 1) { r = b[0]; g = b[1]; bl = b[2]; }
+        else {
+            float X = 0.0f, Y = 0.0f, Z = 0.0f;
+            for (int j = 0; j < S; j++) {
+                X = X + xyz[3 * j + 0] * b[j];
+                Y = Y + xyz[3 * j + 1] * b[j];
+                Z = Z + xyz[3 * j + 2] * b[j];
+            }
+            r  = 3.240479f * X - 1.537150f * Y - 0.498535f * Z;
+            g  = -0.969256f * X + 1.875991f * Y + 0.041556f * Z;
+            bl = 0.055648f * X - 0.204043f * Y + 1.057311f * Z;
+            float mx = fmaxf(r, fmaxf(g, bl));
+            if (mx > 1) { r = r / mx; g = g / mx; bl = bl / mx; }
+        }
+        rgb[3 * i] = r; rgb[3 * i + 1] = g; rgb[3 * i + 2] = bl;
+    }
+}
+
+/* corner values of Drawer::interpolate (vs/Drawer.cpp:161-186): mean colour of the patches around each
+ * vertex, summed in adjacency order; vertices no triangle uses (never drawn) give 0 */
+void orc_vertex_colors(int V, const int32_t* off, const int32_t* adj, const float* rgb, float* out) {
+    for (long v = 0; v < V; v++) {
+        float a[3] = { 0.0f, 0.0f, 0.0f };
+        for (int k = off[v]; k < off[v + 1]; k++)
+            for (int c = 0; c < 3; c++) a[c] = a[c] + rgb[3 * (long)adj[k] + c];
+        int n = off[v + 1] - off[v];
+        for (int c = 0; c < 3; c++) out[3 * v + c] = n > 0 ? a[c] / (float)n : 0.0f;
+    }
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -112,6 +112,12 @@ int orc_converge(int N, int S, const float* F, const float* M,
                  const int32_t* mat, float* R, float* B, float threshold,
                  int per_bin, int max_iters, int threads);
 
+/* Display colour: vs/color.h:14-52, vs/Lightning.h:168-183/332-334/406-408,
+ * vs/Drawer.cpp:161-186.  mode 0 BW, 1 RGB, 2 spectral (xyz = S x 3 fit values). */
+void orc_xyz_fit(double wavelength, float out[3]);
+void orc_patch_colors(int N, int S, const float* B, int mode, const float* xyz, float* rgb);
+void orc_vertex_colors(int V, const int32_t* off, const int32_t* adj, const float* rgb, float* out);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

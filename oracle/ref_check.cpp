@@ -10,7 +10,11 @@
  *     cwiseProduct and MatrixXf * VectorXf exactly as vs/Lightning.h:196-226 and
  *     :342-349 write them -> sparse product must equal oracle.c bit for bit.
  *
- * The reference's first-party files themselves are NOT built: triangle_math.cpp
+ *   - the display colour is evaluated through the reference's own
+ *     "visual studio/color.h" (a first-party header that needs nothing but glm),
+ *     included from where it lies, at the call site of vs/Lightning.h:168-183.
+ *
+ * The reference's other first-party files are NOT built: triangle_math.cpp
  * needs <OptiX_world.h> and Lightning.h needs the OptiX Prime class; the OptiX
  * SDK is absent from this image and is not substituted (DESIGN.md "Oracle").
  *
@@ -23,6 +27,8 @@
 #include <glm/glm.hpp>
 #include <Eigen/Dense>
 #include <Eigen/Sparse>
+
+#include "color.h"      /* $(REF)/visual studio/color.h */
 
 namespace {
 
@@ -152,6 +158,34 @@ void ref_light_pass(int N, int S, const float* F, const float* M, const int32_t*
 float ref_sum(int n, const float* x) {
     Eigen::Map<const Eigen::VectorXf> v(x, n);
     return v.sum();
+}
+
+/* daisy_color::cie1931WavelengthToXYZFit (vs/color.h:14-45), as Lightning.h:128-131 tabulates it */
+void ref_xyz_fit(double wavelength, float* out3) {
+    glm::vec3 v = daisy_color::cie1931WavelengthToXYZFit(wavelength);
+    out3[0] = v[0]; out3[1] = v[1]; out3[2] = v[2];
+}
+
+/* SpectralLightning::update_color_cache for one patch (vs/Lightning.h:168-183); the reference leaves
+ * `glm::vec3 xyz;` uninitialised (glm 0.9.8 default constructor), taken as zero here */
+void ref_patch_color_spectral(int S, const float* xyz_per_bin, const float* b, float* rgb3) {
+    glm::vec3 xyz(0.0f, 0.0f, 0.0f);
+    for (int j = 0; j < S; j++)
+        xyz += glm::vec3(xyz_per_bin[3 * j], xyz_per_bin[3 * j + 1], xyz_per_bin[3 * j + 2]) * b[j];
+    glm::vec3 rgb = { 0.0, 0.0, 0.0 };
+    daisy_color::XYZToRGB(xyz, rgb);
+    float maxval = std::fmax(rgb[0], std::fmax(rgb[1], rgb[2]));
+    if (maxval > 1) rgb = { rgb[0] / maxval, rgb[1] / maxval, rgb[2] / maxval };
+    rgb3[0] = rgb[0]; rgb3[1] = rgb[1]; rgb3[2] = rgb[2];
+}
+
+/* one corner of Drawer::interpolate (vs/Drawer.cpp:161-186): sum of the adjacent patches' colours / count */
+void ref_vertex_color(int n_adj, const int32_t* adj, const float* rgb_patches, float* out3) {
+    glm::vec3 a = { 0.f, 0.f, 0.f };
+    for (int k = 0; k < n_adj; k++)
+        a += glm::vec3(rgb_patches[3 * (long)adj[k]], rgb_patches[3 * (long)adj[k] + 1], rgb_patches[3 * (long)adj[k] + 2]);
+    a = a / glm::vec3((size_t)n_adj);
+    out3[0] = a[0]; out3[1] = a[1]; out3[2] = a[2];
 }
 
 }  // extern "C"

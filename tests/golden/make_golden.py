@@ -65,8 +65,32 @@ def main():
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))
 
 
+def display():
+    """Display colours through the reference's own color.h + glm (oracle/_ref): the spectral colour cache
+    (vs/Lightning.h:168-183) and the vertex means of Drawer::interpolate (vs/Drawer.cpp:161-186)."""
+    assert ob.ref_available()
+    g = np.load(os.path.join(OUT, "lightpass_spectral9_eigen.npz"))
+    sc = scenes.cornell_box(128, S=9, fluorescent=True)
+    B = g["B20"].view(np.float32)
+    # three exposure levels: all below 1, mixed, all normalised by their maximum
+    B = np.concatenate([B * np.float32(0.02), B, B * np.float32(40.0)], axis=0)
+    wl = scenes.WAVELENGTHS_9
+    xyz = ob.ref_xyz_fit(wl)
+    rgb = ob.ref_patch_colors_spectral(B, xyz)
+    off, adj = scenes.vertex_adjacency(sc.tri_v, sc.vertices.shape[0])
+    vtx = ob.ref_vertex_colors(off, adj, rgb[sc.N:2 * sc.N])
+    np.savez_compressed(os.path.join(OUT, "display_color_h.npz"), wavelengths=wl, xyz_bits=xyz.view(np.uint32), B=B,
+                        rgb_bits=rgb.view(np.uint32), tri_v=sc.tri_v, n_vertices=np.int32(sc.vertices.shape[0]),
+                        vtx_off=off, vtx_tri=adj, vertex_rgb_bits=vtx.view(np.uint32))
+    print("wrote display_color_h.npz: %d patches, %d above 1 before normalisation" % (B.shape[0], int((rgb.max(axis=1) >= 1).sum())))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "display":
+        display()
+        sys.exit(0)
     main()
+    display()
 
 
 def reference_scenes():

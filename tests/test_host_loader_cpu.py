@@ -174,3 +174,15 @@ def test_visibility_samples_follow_the_reference_formula(host):
     uv2 = np.zeros((50, 2), np.float32)
     host.drh_visibility_samples(50, 20191, uv2.ctypes.data_as(C.c_void_p))
     assert np.array_equal(uv, uv2)
+
+
+def test_xyz_fit_table_equals_the_reference_header(host):
+    # the host adapter's xyz_per_wavelength (color.h:14-45) against the values the reference's own header gave
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "display_color_h.npz"))
+    host.drh_xyz_fit.argtypes = [C.c_double, C.c_void_p]
+    got = np.zeros((len(g["wavelengths"]), 3), np.float32)
+    for k, w in enumerate(g["wavelengths"]):
+        o = np.zeros(3, np.float32)
+        host.drh_xyz_fit(float(w), o.ctypes.data_as(C.c_void_p))
+        got[k] = o
+    assert np.array_equal(got.view(np.uint32), g["xyz_bits"])

@@ -58,6 +58,25 @@ def test_golden_light_passes_through_eigen(name):
     assert np.allclose(ob.residual_sums(R), g["eigen_sums_R20"], rtol=1e-5, atol=1e-12)
 
 
+def test_golden_display_colours_through_color_h():
+    # vs/color.h:14-52 + vs/Lightning.h:168-183 + vs/Drawer.cpp:161-186, evaluated by the reference's own header
+    g = np.load(os.path.join(GOLD, "display_color_h.npz"))
+    xyz = ob.xyz_fit(g["wavelengths"])
+    assert np.array_equal(_bits(xyz), g["xyz_bits"])
+    rgb = ob.patch_colors(g["B"], 2, xyz)
+    assert np.array_equal(_bits(rgb), g["rgb_bits"])
+    mx = rgb.max(axis=1)
+    assert (mx < 1).any() and (mx == 1).any()              # both branches of the max-normalisation
+    N = g["tri_v"].shape[0]
+    vtx = ob.vertex_colors(g["vtx_off"], g["vtx_tri"], rgb[N:2 * N])
+    assert np.array_equal(_bits(vtx), g["vertex_rgb_bits"])
+    # RGB / BW pass the radiosity through (Lightning.h:332-334, 406-408)
+    B3 = np.ascontiguousarray(g["B"][:, :3])
+    assert np.array_equal(ob.patch_colors(B3, 1), B3)
+    B1 = np.ascontiguousarray(g["B"][:, :1])
+    assert np.array_equal(ob.patch_colors(B1, 0), np.repeat(B1, 3, axis=1))
+
+
 @pytest.mark.skipif(not ob.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
 def test_against_vendored_glm_and_eigen_live():
     sc = scenes.cornell_box(150, S=8, fluorescent=True)
