@@ -510,3 +510,46 @@ def test_bench_size_64k_properties(uv50):
         Bo = E[50000:50064].copy()
         Ro = ob.sweep_rows(Fs, sc.M, sc.mat_of_patch, E, Bo, row0=50000)
         assert (np.abs(R1[50000:50064] - Ro) / (np.abs(Ro).max(axis=0) + 1e-30)).max() < 2e-5
+
+
+def test_c5_shard_256k_fluorescent(uv50):
+    """BASELINE.json's largest configuration on one card: 262 144 patches, 8 bins with fluorescent cross-bin
+    transfer, rank 5 of an 8-way row shard (32 768 x 262 144 floats = 34.4 GB of F).  Spot rows against the
+    oracle (exact), matrix properties, one light pass of sampled rows against the oracle."""
+    sc = scenes.cornell_box(262144, S=8, fluorescent=True)
+    N = sc.N
+    assert N == 262144 and np.abs(sc.M - sc.M * np.eye(8, dtype=np.float32)).max() > 0      # a cross-bin column exists
+    E = sc.emission(7.0)
+    m = _mesh(sc)
+    rank, world = 5, 8
+    with api.Context(0) as c:
+        c.set_shard(rank, world)
+        c.comm_manual()
+        c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+        row0, nrows, rpr = c.shard()
+        assert (row0, nrows, rpr) == (5 * 32768, 32768, 32768)
+        c.assemble(uv50, keep_visibility=True)
+        info = c.info()
+        assert info.bytes_F == 4 * nrows * N
+        r = row0 + nrows - 4                                 # the last rows of the shard (one oracle call: ~40 s of CPU)
+        Fo, viso, _ = ob.assemble_rows(m, uv50, row0=r, nrows=4, bvh=True)
+        assert np.array_equal(c.read_visibility(r, 4), viso)
+        assert np.array_equal(_bits(c.read_rows(r, 4)), _bits(Fo))
+        rows = c.read_rows(row0 + 9000, 128)
+        assert np.isfinite(rows).all() and (rows >= 0).all()
+        assert np.all(rows[np.arange(128), row0 + 9000 + np.arange(128)] == 0)
+        assert 0.9 < rows.sum(axis=1).mean() < 1.1
+        # the block on the diagonal of this shard is symmetric in its ray counts
+        va = c.read_visibility(row0 + 100, 64)[:, row0 + 20000:row0 + 20064]
+        vb = c.read_visibility(row0 + 20000, 64)[:, row0 + 100:row0 + 164]
+        assert np.array_equal(va, vb.T)
+        c.solver_init(E, sc.M, sc.mat_of_patch)
+        c.step(1)
+        B1, _ = c.read(R=False)
+        r = row0 + 30000
+        Fs = c.read_rows(r, 48)
+        Bo = E[r:r + 48].copy()
+        Ro = ob.sweep_rows(Fs, sc.M, sc.mat_of_patch, E, Bo, row0=r)
+        assert (np.abs(B1[r:r + 48] - Bo) / (np.abs(Bo).max(axis=0) + 1e-30)).max() < 2e-5
+        own = c.exchange_export().reshape(8, rpr)           # this rank's new residual chunk, bin-major
+        assert (np.abs(own[:, 30000:30048].T - Ro) / (np.abs(Ro).max(axis=0) + 1e-30)).max() < 2e-5
