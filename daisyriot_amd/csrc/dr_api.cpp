@@ -285,7 +285,7 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     HIPCHK(hipMalloc(&c->d_tri, sizeof(TriRec) * (size_t)N));
     HIPCHK(hipMalloc(&c->d_tri_sorted, sizeof(TriRec) * ((size_t)N + LEAF_MAX)));
     c->n_nodes = 2 * N - 1;
-    HIPCHK(hipMalloc(&c->d_bvh, sizeof(BvhNode) * (size_t)c->n_nodes));
+    HIPCHK(hipMalloc(&c->d_bvh, sizeof(BvhNode) * ((size_t)c->n_nodes + 1)));     // + the sentinel
     HIPCHK(hipMemcpyAsync(c->d_vtx, vertices, sizeof(float) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_nrm, normals, sizeof(float) * 3 * (size_t)Nn, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_tv, tv, sizeof(int) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
@@ -608,6 +608,8 @@ int dr_debug_read_bvh(dr_context* c, void* out, int max_nodes) {
     if (!out || max_nodes < c->n_nodes) return fail(DR_ERR_INVALID, "need room for %d nodes", c->n_nodes);
     HIPCHK(hipMemcpyAsync(out, c->d_bvh, sizeof(BvhNode) * (size_t)c->n_nodes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    BvhNode* nd = (BvhNode*)out;            // skips are kept as byte offsets on the device: report node indices
+    for (int i = 0; i < c->n_nodes; i++) nd[i].skip /= (int)sizeof(BvhNode);
     return DR_OK;
 }
 

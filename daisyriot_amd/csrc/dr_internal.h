@@ -28,12 +28,15 @@ struct TriRec {
 
 
 // Threaded BVH node in depth-first pre-order: the first child of an internal node is
-// node+1; `skip` is the pre-order index of the first node after this node's subtree.
+// node+1; `skip` is the BYTE offset (pre-order index * 32) of the first node after this node's subtree.
+// The array ends with one sentinel node (all-space box, tri = BVH_END) that every skip out of the tree
+// lands on.
 struct BvhNode {
     float lo[3], hi[3];
     int   skip;
     int   tri;          // leaf: first*8 + (count-1) into the Morton-ordered TriRec array; -1: internal
 };                      // 32 B: one s_load_dwordx8
+constexpr int BVH_END = 0x7ffffff8;
 
 constexpr int LEAF_MAX = 2;     // subtrees of up to this many triangles are collapsed into one leaf
                                 // (a leaf is fetched whole: LEAF_MAX x 16 SGPRs)

@@ -235,7 +235,7 @@ __global__ void k_emit(int N, const int* __restrict__ left, const int* __restric
     BvhNode nd;
     const float* b = box + 6 * (size_t)id;
     for (int a = 0; a < 3; a++) { nd.lo[a] = b[a]; nd.hi[a] = b[3 + a]; }
-    nd.skip = idx + esize[id];
+    nd.skip = (idx + esize[id]) * (int)sizeof(BvhNode);
     nd.tri = (cnt <= LEAF_MAX) ? f * 8 + (cnt - 1) : -1;
     nodes[idx] = nd;
 }
@@ -295,6 +295,14 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
         DR_TRY(hipGetLastError());
         // nodes written = size of the root's subtree (a lone triangle is its own root leaf)
         DR_TRY(hipMemcpyAsync(n_nodes_out, esize, sizeof(int), hipMemcpyDeviceToHost, st));
+        DR_TRY(hipStreamSynchronize(st));
+        // the walk has no bound check: every skip that leaves the tree lands on this node, an all-space box
+        // that every live ray hits and whose leaf code says "end" (see walk_bvh)
+        BvhNode endn;
+        for (int a = 0; a < 3; a++) { endn.lo[a] = -INFINITY; endn.hi[a] = INFINITY; }
+        endn.skip = (*n_nodes_out + 1) * (int)sizeof(BvhNode);
+        endn.tri = BVH_END;
+        DR_TRY(hipMemcpyAsync(nodes + *n_nodes_out, &endn, sizeof(BvhNode), hipMemcpyHostToDevice, st));
         DR_TRY(hipStreamSynchronize(st));
     }
 #undef DR_TRY
@@ -394,33 +402,87 @@ __device__ __forceinline__ void integrand_pair(const float* ri, const float* rj,
 // Walk of the threaded BVH for one wave of rays (segments [0,tmax] from org along dn); returns the
 // liveness mask with every lane cleared whose closest hit is not its destination `hi` (wave-uniform
 // int in the one-pair-per-wave path, per-lane int in the packed path).
+//
+// The node index is wave-uniform, so the walk is paced by the CU's single scalar unit (it serves all four
+// SIMDs) at least as much as by the vector units: the compiler's lowering of the loop spent ~20 scalar
+// instructions per node beside the 24 vector ones of the slab test.  The interior-node walk is therefore
+// written out by hand: one s_load_dwordx8 of the node at an SGPR byte offset, the slab test on the SGPR
+// box (the same 24 operations, in the order box_hit_mask compiles to -- the result is the same bit for
+// bit), one s_and with the liveness mask whose SCC is the branch condition, and then either
+// offset += 32 (descend: the first child is the next node in pre-order) or offset = skip.  7 scalar
+// instructions for a node that is entered, 6 for one that is skipped.  There is no end-of-tree compare:
+// skips that leave the tree land on the sentinel node (all-space box, leaf code BVH_END), which every live
+// lane hits; the hand-written stretch ends whenever a hit node is a leaf.
 template <bool STATS, typename HiT>
 __device__ __forceinline__ unsigned long long walk_bvh(const BvhNode* __restrict__ bvh, const TriRec* __restrict__ tri_sorted,
                                                        int n_nodes_i, f3 org, f3 dn, f3 inv, float tmax, HiT hi,
                                                        unsigned long long alive_m, int& n_visit, int& n_leaf) {
-    // Walk the threaded BVH with a wave-uniform node index.  The scalar unit (one per CU)
-    // carries as many instructions as the vector units here, so the step is kept minimal:
-    // one scalar node load at an SGPR offset, one slab test ending in a single v_cmp, one
-    // s_and with the liveness mask; the "any lane still alive" test only runs after a leaf
-    // could have retired lanes.  Every step moves forward in pre-order, so the walk ends.
-    const unsigned n_nodes = (unsigned)n_nodes_i;
-    unsigned node = (alive_m == 0ull) ? n_nodes : 0u;
-    while (node < n_nodes) {
-        // the whole 32-byte node in one scalar load (field-wise loads would chain latencies)
-        // (float vector + __float_as_int: __builtin_bit_cast on a vector ELEMENT reads element 0)
-        // base + 32-bit byte offset: selects the SGPR-offset form of s_load (no 64-bit address math)
-        const v8f raw = *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(bvh) + node * 32u);
-        BvhNode nd;
-        nd.lo[0] = raw[0]; nd.lo[1] = raw[1]; nd.lo[2] = raw[2];
-        nd.hi[0] = raw[3]; nd.hi[1] = raw[4]; nd.hi[2] = raw[5];
-        const int nd_skip = __builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
-        const int leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
-        if (STATS) n_visit++;
-        // the slab test runs for every lane, dead ones are masked after
-        const unsigned long long hb_m = box_hit_mask(nd.lo, nd.hi, org, inv, tmax) & alive_m;
-        if (hb_m == 0ull) { node = max((unsigned)nd_skip, node + 1u); continue; }
-        node = node + 1;
-        if (leaf < 0) continue;
+    if (alive_m == 0ull) return 0ull;
+    unsigned off = 0u;          // byte offset of the next node to visit
+    for (;;) {
+        int leaf;
+        if (STATS) {
+            // counted variant of the same walk (debug builds only)
+            for (;;) {
+                const v8f raw = *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(bvh) + off);
+                const float nlo[3] = { raw[0], raw[1], raw[2] }, nhi[3] = { raw[3], raw[4], raw[5] };
+                const unsigned nd_skip = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
+                leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
+                n_visit++;
+                const unsigned long long hb_m = box_hit_mask(nlo, nhi, org, inv, tmax) & alive_m;
+                if (hb_m == 0ull) { off = nd_skip; continue; }
+                off += 32u;
+                if (leaf >= 0) break;
+            }
+            (void)n_nodes_i;
+        } else {
+            float t0, t1, t2, t3, t4, t5;
+            asm volatile(
+                "1:\n\t"
+                "s_load_dwordx8 s[88:95], %[bvh], %[off] offset:0x0\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_sub_f32_e32 %[t0], s88, %[ox]\n\t"
+                "v_sub_f32_e32 %[t1], s91, %[ox]\n\t"
+                "v_sub_f32_e32 %[t2], s89, %[oy]\n\t"
+                "v_mul_f32_e32 %[t0], %[ix], %[t0]\n\t"
+                "v_mul_f32_e32 %[t1], %[ix], %[t1]\n\t"
+                "v_min_f32_e32 %[t3], %[t0], %[t1]\n\t"
+                "v_max_f32_e32 %[t0], %[t0], %[t1]\n\t"
+                "v_mul_f32_e32 %[t1], %[iy], %[t2]\n\t"
+                "v_sub_f32_e32 %[t2], s92, %[oy]\n\t"
+                "v_mul_f32_e32 %[t2], %[iy], %[t2]\n\t"
+                "v_min_f32_e32 %[t4], %[t1], %[t2]\n\t"
+                "v_max_f32_e32 %[t3], %[t3], %[t4]\n\t"
+                "v_max_f32_e32 %[t1], %[t1], %[t2]\n\t"
+                "v_sub_f32_e32 %[t2], s90, %[oz]\n\t"
+                "v_sub_f32_e32 %[t4], s93, %[oz]\n\t"
+                "v_mul_f32_e32 %[t2], %[iz], %[t2]\n\t"
+                "v_mul_f32_e32 %[t4], %[iz], %[t4]\n\t"
+                "v_min_f32_e32 %[t5], %[t2], %[t4]\n\t"
+                "v_max_f32_e32 %[t2], %[t2], %[t4]\n\t"
+                "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t"
+                "v_mul_f32_e32 %[t0], 0x3f800054, %[t0]\n\t"
+                "v_max3_f32 %[t3], %[t3], %[t5], 0\n\t"
+                "v_min_f32_e32 %[t0], %[t0], %[tmax]\n\t"
+                "v_cmp_le_f32_e32 vcc, %[t3], %[t0]\n\t"
+                "s_and_b64 vcc, vcc, %[alive]\n\t"
+                "s_cbranch_scc0 3f\n\t"
+                "s_add_u32 %[off], %[off], 32\n\t"
+                "s_cmp_lt_i32 s95, 0\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                "s_branch 2f\n"
+                "3:\n\t"
+                "s_mov_b32 %[off], s94\n\t"
+                "s_branch 1b\n"
+                "2:\n\t"
+                "s_mov_b32 %[leaf], s95"
+                : [off] "+s"(off), [leaf] "=s"(leaf), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
+                  [t4] "=&v"(t4), [t5] "=&v"(t5)
+                : [bvh] "s"(bvh), [alive] "s"(alive_m), [ox] "v"(org.x), [oy] "v"(org.y), [oz] "v"(org.z), [ix] "v"(inv.x),
+                  [iy] "v"(inv.y), [iz] "v"(inv.z), [tmax] "v"(tmax)
+                : "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "vcc", "scc");
+        }
+        if (leaf == BVH_END) break;
         if (STATS) n_leaf++;
         const int first = leaf >> 3, cnt = (leaf & 7) + 1;
         // Leaf: its LEAF_MAX records (64 B each: triangle, id, gate box) are fetched together --
