@@ -285,7 +285,7 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     HIPCHK(hipMalloc(&c->d_tri, sizeof(TriRec) * (size_t)N));
     HIPCHK(hipMalloc(&c->d_tri_sorted, sizeof(TriRec) * ((size_t)N + LEAF_MAX)));
     c->n_nodes = 2 * N - 1;
-    HIPCHK(hipMalloc(&c->d_bvh, sizeof(BvhNode) * ((size_t)c->n_nodes + 1)));     // + the sentinel
+    HIPCHK(hipMalloc(&c->d_bvh, sizeof(BvhNode) * ((size_t)c->n_nodes + 2)));     // + the sentinel + one node the walk's prefetch may touch
     HIPCHK(hipMemcpyAsync(c->d_vtx, vertices, sizeof(float) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_nrm, normals, sizeof(float) * 3 * (size_t)Nn, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_tv, tv, sizeof(int) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
@@ -297,7 +297,16 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, c->stream));
-    hipError_t be = build_lbvh(c->stream, N, c->d_tri, lo, hi, c->d_bvh, c->d_tri_sorted, &c->n_nodes);
+    // growth of every BVH node box that makes the cheap node test conservative (node_hit_mask, geom_kernels.hip)
+    float diag2 = 0.0f, maxabs = 0.0f;
+    for (int a = 0; a < 3; a++) {
+        const float ext = (hi[a] - lo[a]) + 2.0f * box_pad;
+        diag2 += ext * ext;
+        maxabs = std::max(maxabs, std::max(std::fabs(lo[a]), std::fabs(hi[a])) + box_pad);
+    }
+    if (!(maxabs < 1e15f)) return fail(DR_ERR_INVALID, "scene coordinates up to %g exceed the supported 1e15", (double)maxabs);
+    const float node_pad = 3e-5f * std::sqrt(diag2) + 4e-6f * maxabs;
+    hipError_t be = build_lbvh(c->stream, N, c->d_tri, lo, hi, node_pad, c->d_bvh, c->d_tri_sorted, &c->n_nodes);
     if (be != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return fail(DR_ERR_DEVICE, "LBVH build failed: %s", hipGetErrorString(be)); }
     HIPCHK(hipEventRecord(e1, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -608,8 +617,11 @@ int dr_debug_read_bvh(dr_context* c, void* out, int max_nodes) {
     if (!out || max_nodes < c->n_nodes) return fail(DR_ERR_INVALID, "need room for %d nodes", c->n_nodes);
     HIPCHK(hipMemcpyAsync(out, c->d_bvh, sizeof(BvhNode) * (size_t)c->n_nodes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    BvhNode* nd = (BvhNode*)out;            // skips are kept as byte offsets on the device: report node indices
-    for (int i = 0; i < c->n_nodes; i++) nd[i].skip /= (int)sizeof(BvhNode);
+    BvhNode* nd = (BvhNode*)out;            // device form: centre/half-extent, skips as byte offsets; reported: lo/hi, node indices
+    for (int i = 0; i < c->n_nodes; i++) {
+        nd[i].skip /= (int)sizeof(BvhNode);
+        for (int a = 0; a < 3; a++) { const float ce = nd[i].c[a], he = nd[i].h[a]; nd[i].c[a] = ce - he; nd[i].h[a] = ce + he; }
+    }
     return DR_OK;
 }
 

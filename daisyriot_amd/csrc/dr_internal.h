@@ -29,10 +29,11 @@ struct TriRec {
 
 // Threaded BVH node in depth-first pre-order: the first child of an internal node is
 // node+1; `skip` is the BYTE offset (pre-order index * 32) of the first node after this node's subtree.
+// The box is held as centre and half-extent, grown by the build's node_pad (see node_hit_mask).
 // The array ends with one sentinel node (all-space box, tri = BVH_END) that every skip out of the tree
 // lands on.
 struct BvhNode {
-    float lo[3], hi[3];
+    float c[3], h[3];
     int   skip;
     int   tri;          // leaf: first*8 + (count-1) into the Morton-ordered TriRec array; -1: internal
 };                      // 32 B: one s_load_dwordx8
@@ -85,7 +86,7 @@ struct SweepParams {
 hipError_t launch_patch_records(hipStream_t st, int N, const float* vtx, const float* nrm,
                                 const int* tv, const int* tn, float box_pad, PatchRec* patch, TriRec* tri);
 hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float scene_lo[3],
-                      const float scene_hi[3], BvhNode* nodes /* room for 2N-1 */,
+                      const float scene_hi[3], float node_pad, BvhNode* nodes /* room for 2N */,
                       TriRec* tri_sorted /* N + LEAF_MAX */, int* n_nodes_out);
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p);
 hipError_t launch_sweep(hipStream_t st, const SweepParams& p);

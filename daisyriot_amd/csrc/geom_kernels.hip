@@ -216,7 +216,7 @@ __global__ void k_refit(int N, const TriRec* __restrict__ tri, const int* __rest
 // plus the written size of every left sibling subtree.
 __global__ void k_emit(int N, const int* __restrict__ left, const int* __restrict__ first,
                        const int* __restrict__ last, const int* __restrict__ parent,
-                       const float* __restrict__ box, const int* __restrict__ esize,
+                       const float* __restrict__ box, const int* __restrict__ esize, float node_pad,
                        BvhNode* __restrict__ nodes) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= 2 * N - 1) return;
@@ -234,7 +234,13 @@ __global__ void k_emit(int N, const int* __restrict__ left, const int* __restric
     }
     BvhNode nd;
     const float* b = box + 6 * (size_t)id;
-    for (int a = 0; a < 3; a++) { nd.lo[a] = b[a]; nd.hi[a] = b[3 + a]; }
+    for (int a = 0; a < 3; a++) {
+        // centre and half-extent of a box that contains [lo - node_pad, hi + node_pad] whatever the roundings
+        const float c = 0.5f * b[a] + 0.5f * b[3 + a];
+        const float h = fmaxf(b[3 + a] - c, c - b[a]);
+        nd.c[a] = c;
+        nd.h[a] = h * 1.000001f + node_pad;
+    }
     nd.skip = (idx + esize[id]) * (int)sizeof(BvhNode);
     nd.tri = (cnt <= LEAF_MAX) ? f * 8 + (cnt - 1) : -1;
     nodes[idx] = nd;
@@ -250,7 +256,7 @@ __global__ void k_pad_tris(int N, TriRec* __restrict__ tri_sorted) {
     }
 }
 
-hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[3], const float shi[3],
+hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[3], const float shi[3], float node_pad,
                       BvhNode* nodes, TriRec* tri_sorted, int* n_nodes_out) {
     hipError_t e;
     unsigned long long *keys = nullptr, *keys2 = nullptr;
@@ -291,7 +297,7 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
         DR_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_pad_tris, dim3(1), dim3(64), 0, st, N, tri_sorted);
         DR_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_emit, dim3((int)((nn + 255) / 256)), dim3(256), 0, st, N, left, first, last, parent, box, esize, nodes);
+        hipLaunchKernelGGL(k_emit, dim3((int)((nn + 255) / 256)), dim3(256), 0, st, N, left, first, last, parent, box, esize, node_pad, nodes);
         DR_TRY(hipGetLastError());
         // nodes written = size of the root's subtree (a lone triangle is its own root leaf)
         DR_TRY(hipMemcpyAsync(n_nodes_out, esize, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -299,7 +305,7 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
         // the walk has no bound check: every skip that leaves the tree lands on this node, an all-space box
         // that every live ray hits and whose leaf code says "end" (see walk_bvh)
         BvhNode endn;
-        for (int a = 0; a < 3; a++) { endn.lo[a] = -INFINITY; endn.hi[a] = INFINITY; }
+        for (int a = 0; a < 3; a++) { endn.c[a] = 0.0f; endn.h[a] = INFINITY; }
         endn.skip = (*n_nodes_out + 1) * (int)sizeof(BvhNode);
         endn.tri = BVH_END;
         DR_TRY(hipMemcpyAsync(nodes + *n_nodes_out, &endn, sizeof(BvhNode), hipMemcpyHostToDevice, st));
@@ -355,6 +361,28 @@ __device__ __forceinline__ float safe_inv(float d) {
     return d == 0.0f ? 3.0e38f : 1.0f / d;
 }
 
+// Conservative test of the segment [0,tmax] against a BVH NODE (centre c, half-extent h in SGPRs), as a wave mask.
+// A node test only has to be conservative -- what is hit is decided per triangle by its gate (box_hit_mask) and
+// Moller-Trumbore -- so it need not be the gate's own arithmetic, only never reject a node one of whose
+// triangles' gates accepts.  This form costs 14 vector instructions instead of 24:
+//     tc = fma(c, iv, k)            k = -(org*iv), iv = the ray's 1/d clamped to +-1e18 (per ray, once)
+//     tn = fma(h, -|iv|, tc)        tf = fma(h, |iv|, tc)          per axis, no plane selection, no min/max
+//     accept  <=>  max(tn_x, tn_y, tn_z, 0) <= min(tf_x, tf_y, tf_z, tmax)
+// Its rounding errors (fma form: up to 6 ulp of (|c|+|org|+h)*|iv|) and the slack the gate test grants
+// (tf*1.00001, i.e. a miss by up to 1.1e-5 of the ray length) are both bounded by a DISTANCE times |iv|, so
+// they are absorbed by growing every node box once, at build time, by
+//     node_pad = 3e-5 * scene diagonal + 4e-6 * max|coordinate|
+// (needed: 1.2e-5 D + 1e-6 M; DESIGN.md section 4 has the derivation).  The clamp keeps c*iv and org*iv
+// finite for axis-parallel rays (iv = 3e38 from safe_inv); with |iv| = 1e18 the padded slab still spans
+// [0,tmax] whenever the origin lies within it.
+__device__ __forceinline__ unsigned long long node_hit_mask(const float c[3], const float h[3], f3 iv, f3 k, float tmax) {
+    const float tcx = __builtin_fmaf(c[0], iv.x, k.x), tcy = __builtin_fmaf(c[1], iv.y, k.y), tcz = __builtin_fmaf(c[2], iv.z, k.z);
+    const float ax = fabsf(iv.x), ay = fabsf(iv.y), az = fabsf(iv.z);
+    const float tn = fmaxf(fmaxf(fmaxf(__builtin_fmaf(h[0], -ax, tcx), __builtin_fmaf(h[1], -ay, tcy)), __builtin_fmaf(h[2], -az, tcz)), 0.0f);
+    const float tf = fminf(fminf(fminf(__builtin_fmaf(h[0], ax, tcx), __builtin_fmaf(h[1], ay, tcy)), __builtin_fmaf(h[2], az, tcz)), tmax);
+    return __builtin_amdgcn_fcmpf(tn, tf, 5);
+}
+
 // ---------------------------------------------------------------------------------------
 // fused tile kernel
 // ---------------------------------------------------------------------------------------
@@ -403,21 +431,23 @@ __device__ __forceinline__ void integrand_pair(const float* ri, const float* rj,
 // liveness mask with every lane cleared whose closest hit is not its destination `hi` (wave-uniform
 // int in the one-pair-per-wave path, per-lane int in the packed path).
 //
-// The node index is wave-uniform, so the walk is paced by the CU's single scalar unit (it serves all four
-// SIMDs) at least as much as by the vector units: the compiler's lowering of the loop spent ~20 scalar
-// instructions per node beside the 24 vector ones of the slab test.  The interior-node walk is therefore
-// written out by hand: one s_load_dwordx8 of the node at an SGPR byte offset, the slab test on the SGPR
-// box (the same 24 operations, in the order box_hit_mask compiles to -- the result is the same bit for
-// bit), one s_and with the liveness mask whose SCC is the branch condition, and then either
-// offset += 32 (descend: the first child is the next node in pre-order) or offset = skip.  7 scalar
-// instructions for a node that is entered, 6 for one that is skipped.  There is no end-of-tree compare:
-// skips that leave the tree land on the sentinel node (all-space box, leaf code BVH_END), which every live
-// lane hits; the hand-written stretch ends whenever a hit node is a leaf.
+// The node index is wave-uniform.  The compiler's lowering of this loop spent ~20 scalar instructions per
+// node (the CU's single scalar unit serves all four SIMDs) beside the vector ones, so the interior-node
+// walk is written out by hand: one s_load_dwordx8 of the node at an SGPR byte offset, the 14-instruction
+// node test (node_hit_mask), one s_and with the liveness mask whose SCC is the branch condition, then
+// either offset += 32 (descend: the first child is the next node in pre-order) or offset = skip --
+// 7 scalar instructions for a node that is entered, 6 for one that is skipped.  There is no end-of-tree
+// compare: skips that leave the tree land on the sentinel node (all-space box, leaf code BVH_END), which
+// every live lane hits; the hand-written stretch ends whenever a hit node is a leaf.
 template <bool STATS, typename HiT>
 __device__ __forceinline__ unsigned long long walk_bvh(const BvhNode* __restrict__ bvh, const TriRec* __restrict__ tri_sorted,
                                                        int n_nodes_i, f3 org, f3 dn, f3 inv, float tmax, HiT hi,
                                                        unsigned long long alive_m, int& n_visit, int& n_leaf) {
     if (alive_m == 0ull) return 0ull;
+    // per-ray constants of the node test
+    const f3 iv = f3{ __builtin_amdgcn_fmed3f(inv.x, -1e18f, 1e18f), __builtin_amdgcn_fmed3f(inv.y, -1e18f, 1e18f),
+                      __builtin_amdgcn_fmed3f(inv.z, -1e18f, 1e18f) };
+    const f3 kk = f3{ -(org.x * iv.x), -(org.y * iv.y), -(org.z * iv.z) };
     unsigned off = 0u;          // byte offset of the next node to visit
     for (;;) {
         int leaf;
@@ -425,11 +455,11 @@ __device__ __forceinline__ unsigned long long walk_bvh(const BvhNode* __restrict
             // counted variant of the same walk (debug builds only)
             for (;;) {
                 const v8f raw = *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(bvh) + off);
-                const float nlo[3] = { raw[0], raw[1], raw[2] }, nhi[3] = { raw[3], raw[4], raw[5] };
+                const float nc[3] = { raw[0], raw[1], raw[2] }, nh[3] = { raw[3], raw[4], raw[5] };
                 const unsigned nd_skip = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
                 leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
                 n_visit++;
-                const unsigned long long hb_m = box_hit_mask(nlo, nhi, org, inv, tmax) & alive_m;
+                const unsigned long long hb_m = node_hit_mask(nc, nh, iv, kk, tmax) & alive_m;
                 if (hb_m == 0ull) { off = nd_skip; continue; }
                 off += 32u;
                 if (leaf >= 0) break;
@@ -437,50 +467,69 @@ __device__ __forceinline__ unsigned long long walk_bvh(const BvhNode* __restrict
             (void)n_nodes_i;
         } else {
             float t0, t1, t2, t3, t4, t5;
-            asm volatile(
-                "1:\n\t"
-                "s_load_dwordx8 s[88:95], %[bvh], %[off] offset:0x0\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "v_sub_f32_e32 %[t0], s88, %[ox]\n\t"
-                "v_sub_f32_e32 %[t1], s91, %[ox]\n\t"
-                "v_sub_f32_e32 %[t2], s89, %[oy]\n\t"
-                "v_mul_f32_e32 %[t0], %[ix], %[t0]\n\t"
-                "v_mul_f32_e32 %[t1], %[ix], %[t1]\n\t"
-                "v_min_f32_e32 %[t3], %[t0], %[t1]\n\t"
-                "v_max_f32_e32 %[t0], %[t0], %[t1]\n\t"
-                "v_mul_f32_e32 %[t1], %[iy], %[t2]\n\t"
-                "v_sub_f32_e32 %[t2], s92, %[oy]\n\t"
-                "v_mul_f32_e32 %[t2], %[iy], %[t2]\n\t"
-                "v_min_f32_e32 %[t4], %[t1], %[t2]\n\t"
-                "v_max_f32_e32 %[t3], %[t3], %[t4]\n\t"
-                "v_max_f32_e32 %[t1], %[t1], %[t2]\n\t"
-                "v_sub_f32_e32 %[t2], s90, %[oz]\n\t"
-                "v_sub_f32_e32 %[t4], s93, %[oz]\n\t"
-                "v_mul_f32_e32 %[t2], %[iz], %[t2]\n\t"
-                "v_mul_f32_e32 %[t4], %[iz], %[t4]\n\t"
-                "v_min_f32_e32 %[t5], %[t2], %[t4]\n\t"
-                "v_max_f32_e32 %[t2], %[t2], %[t4]\n\t"
-                "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t"
-                "v_mul_f32_e32 %[t0], 0x3f800054, %[t0]\n\t"
-                "v_max3_f32 %[t3], %[t3], %[t5], 0\n\t"
-                "v_min_f32_e32 %[t0], %[t0], %[tmax]\n\t"
-                "v_cmp_le_f32_e32 vcc, %[t3], %[t0]\n\t"
+            // two copies of the step, on node registers A = s[88:95] and B = s[80:87]: while one node is tested the
+            // next one in pre-order (the first child, where a hit descends to) is already being fetched into the
+            // other set; a miss reloads its own set from the skip offset.
+#define DR_NODE_TEST(CX, CY, CZ, HX, HY, HZ)                                  \
+                "v_fma_f32 %[t0], " CX ", %[ix], %[kx]\n\t"                   \
+                "v_fma_f32 %[t1], " CY ", %[iy], %[ky]\n\t"                   \
+                "v_fma_f32 %[t2], " CZ ", %[iz], %[kz]\n\t"                   \
+                "v_fma_f32 %[t3], " HX ", -|%[ix]|, %[t0]\n\t"                \
+                "v_fma_f32 %[t0], " HX ", |%[ix]|, %[t0]\n\t"                 \
+                "v_fma_f32 %[t4], " HY ", -|%[iy]|, %[t1]\n\t"                \
+                "v_fma_f32 %[t1], " HY ", |%[iy]|, %[t1]\n\t"                 \
+                "v_fma_f32 %[t5], " HZ ", -|%[iz]|, %[t2]\n\t"                \
+                "v_fma_f32 %[t2], " HZ ", |%[iz]|, %[t2]\n\t"                 \
+                "v_max3_f32 %[t3], %[t3], %[t4], %[t5]\n\t"                   \
+                "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t"                   \
+                "v_max_f32_e32 %[t3], 0, %[t3]\n\t"                           \
+                "v_min_f32_e32 %[t0], %[t0], %[tmax]\n\t"                     \
+                "v_cmp_le_f32_e32 vcc, %[t3], %[t0]\n\t"                      \
                 "s_and_b64 vcc, vcc, %[alive]\n\t"
+            asm volatile(
+                "s_load_dwordx8 s[88:95], %[bvh], %[off] offset:0x0\n\t"
+                "s_waitcnt lgkmcnt(0)\n"
+                "1:\n\t"
+                "s_load_dwordx8 s[80:87], %[bvh], %[off] offset:0x20\n\t"
+                DR_NODE_TEST("s88", "s89", "s90", "s91", "s92", "s93")
                 "s_cbranch_scc0 3f\n\t"
                 "s_add_u32 %[off], %[off], 32\n\t"
                 "s_cmp_lt_i32 s95, 0\n\t"
-                "s_cbranch_scc1 1b\n\t"
-                "s_branch 2f\n"
+                "s_cbranch_scc0 5f\n\t"
+                "s_waitcnt lgkmcnt(0)\n"
+                "2:\n\t"
+                "s_load_dwordx8 s[88:95], %[bvh], %[off] offset:0x20\n\t"
+                DR_NODE_TEST("s80", "s81", "s82", "s83", "s84", "s85")
+                "s_cbranch_scc0 4f\n\t"
+                "s_add_u32 %[off], %[off], 32\n\t"
+                "s_cmp_lt_i32 s87, 0\n\t"
+                "s_cbranch_scc0 6f\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "s_branch 1b\n"
                 "3:\n\t"
                 "s_mov_b32 %[off], s94\n\t"
+                "s_load_dwordx8 s[88:95], %[bvh], %[off] offset:0x0\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
                 "s_branch 1b\n"
-                "2:\n\t"
-                "s_mov_b32 %[leaf], s95"
+                "4:\n\t"
+                "s_mov_b32 %[off], s86\n\t"
+                "s_load_dwordx8 s[80:87], %[bvh], %[off] offset:0x0\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "s_branch 2b\n"
+                "5:\n\t"
+                "s_mov_b32 %[leaf], s95\n\t"
+                "s_branch 7f\n"
+                "6:\n\t"
+                "s_mov_b32 %[leaf], s87\n"
+                "7:\n\t"
+                "s_waitcnt lgkmcnt(0)"
                 : [off] "+s"(off), [leaf] "=s"(leaf), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
                   [t4] "=&v"(t4), [t5] "=&v"(t5)
-                : [bvh] "s"(bvh), [alive] "s"(alive_m), [ox] "v"(org.x), [oy] "v"(org.y), [oz] "v"(org.z), [ix] "v"(inv.x),
-                  [iy] "v"(inv.y), [iz] "v"(inv.z), [tmax] "v"(tmax)
-                : "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "vcc", "scc");
+                : [bvh] "s"(bvh), [alive] "s"(alive_m), [kx] "v"(kk.x), [ky] "v"(kk.y), [kz] "v"(kk.z), [ix] "v"(iv.x),
+                  [iy] "v"(iv.y), [iz] "v"(iv.z), [tmax] "v"(tmax)
+                : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94",
+                  "s95", "vcc", "scc");
+#undef DR_NODE_TEST
         }
         if (leaf == BVH_END) break;
         if (STATS) n_leaf++;
