@@ -61,6 +61,16 @@ long drh_ini_integer(drh_ini* h, const char* sec, const char* name, long def) { 
 double drh_ini_real(drh_ini* h, const char* sec, const char* name, double def) { return h->r.GetReal(sec, name, def); }
 int drh_ini_boolean(drh_ini* h, const char* sec, const char* name, int def) { return h->r.GetBoolean(sec, name, def != 0) ? 1 : 0; }
 
+// Material::rgb_to_spectrum (Material.cpp:35-45) through the table at `coeff_path`; returns 1 if the table was
+// found (0: the smooth stand-in spectrum was used)
+int drh_upsample(const char* coeff_path, const float* rgb, const float* wavelengths, int S, float* out) {
+    SpectralUpsampler up(coeff_path);
+    std::vector<float> wl(wavelengths, wavelengths + S), sp;
+    up.spectrum(vec3{ rgb[0], rgb[1], rgb[2] }, wl, sp);
+    for (int s = 0; s < S; s++) out[s] = sp[(size_t)s];
+    return up.has_table() ? 1 : 0;
+}
+
 void drh_xyz_fit(double wavelength, float* out3) { vec3 v = cie1931_xyz_fit(wavelength); out3[0] = v.x; out3[1] = v.y; out3[2] = v.z; }
 
 void drh_visibility_samples(int K, unsigned seed, float* uv) {

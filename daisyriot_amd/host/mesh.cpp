@@ -24,8 +24,10 @@ SpectralUpsampler::SpectralUpsampler(const std::string& path) {
         scale_.resize(res);
         data_.resize((size_t)res * res * res * 9);
         if (std::fread(scale_.data(), sizeof(float), res, f) == res &&
-            std::fread(data_.data(), sizeof(float), data_.size(), f) == data_.size())
+            std::fread(data_.data(), sizeof(float), data_.size(), f) == data_.size()) {
             res_ = res;
+            std::printf("Loading \"%s\" .. \n", path.c_str());          // rgb2spec.cpp:22
+        }
     }
     std::fclose(f);
     if (!res_) { scale_.clear(); data_.clear(); }

@@ -107,3 +107,24 @@ def test_spectral_and_bw_methods_run(tmp_path):
     assert d.shape == (300, 5) and np.isfinite(d).all() and "Number of light passes 12." in out
     r = subprocess.run([CLI, str(tmp_path / "missing.ini")], capture_output=True, text=True)
     assert r.returncode == 1 and "Can't load" in r.stdout
+
+
+def test_spectral_scene_with_a_generated_coefficient_table(tmp_path):
+    """color_tables/srgb.coeff (absent from the reference tree) made by lib/rgb2spec_opt and picked up from the
+    working directory exactly where the reference looks for it (Material.cpp:11)"""
+    _write_scene(tmp_path, 300, 2, True)
+    _, d0 = _run(tmp_path, "--no-matfile", "--passes", "4")
+    (tmp_path / "color_tables").mkdir()
+    tool = os.path.join(ROOT, "daisyriot_amd", "lib", "rgb2spec_opt")
+    r = subprocess.run([tool, "16", str(tmp_path / "color_tables" / "srgb.coeff")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = tmp_path / "out.csv"
+    r = subprocess.run([CLI, str(tmp_path / "config.ini"), "--out", str(out), "--no-matfile", "--passes", "4"],
+                       capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    assert 'Loading "color_tables/srgb.coeff"' in r.stdout
+    d1 = np.loadtxt(out, delimiter=",", skiprows=1)
+    assert d1.shape == d0.shape and np.isfinite(d1).all() and (d1[:, 4:] >= 0).all()
+    assert not np.allclose(d1[:, 4:], d0[:, 4:])          # the table's spectra, not the stand-in's
+    # the upsampled reflectances stay below 1: four passes lose energy in every bin that carries any
+    assert d1[:, 4:].sum() > 0
