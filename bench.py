@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BARE_READ_GBS = 7072.0     # what a kernel that only reads 17.18 GB reaches on this part (tools/hbm_probe.hip, profiles/r01/hbm_probe.md)
 
 
 def sweep_bytes(nrows, N, S, n_mat):
@@ -214,6 +215,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(N, S, world),
                          "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": kern_ms,
+                         "bare_read_GBs": BARE_READ_GBS, "frac_of_bare_read": achieved / BARE_READ_GBS,
                          "launches_timed": int(info.sweep_launches)},
             "formfactors": {"value": N * (N - 1) / t_asm, "unit": "pairs/s", "seconds": t_asm,
                             "kernel_seconds": t_asm_kernel, "bvh_build_seconds": t_bvh,

@@ -1,0 +1,76 @@
+// hbm_probe.hip -- what a bare streaming read reaches on this MI355X: the practical ceiling that the light
+// pass (k_sweep, HBM-bound) is measured against next to the 8 TB/s spec peak.
+//   hipcc -O3 --offload-arch=gfx950 -o hbm_probe tools/hbm_probe.hip && ./hbm_probe [GiB]
+// Reads a buffer of the F matrix's size (16 GiB by default) once per launch with 16-byte loads, plain and
+// non-temporal, several unroll depths and grid sizes; prints GB/s per variant (mean of 20 launches).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void k_read(const v4f* __restrict__ src, size_t n_vec, float* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    v4f acc = { 0, 0, 0, 0 };
+    for (; i + (UNROLL - 1) * stride < n_vec; i += UNROLL * stride) {
+        v4f v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) v[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) acc += v[u];
+    }
+    for (; i < n_vec; i += stride) acc += src[i];
+    float s = acc[0] + acc[1] + acc[2] + acc[3];
+    if (s == 12345.678f) out[blockIdx.x] = s;       // keeps the loads alive; practically never true
+}
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+template <int UNROLL, bool NT>
+int run(const v4f* buf, size_t n_vec, float* out, int blocks, double bytes) {
+    hipEvent_t a, b;
+    CHK(hipEventCreate(&a));
+    CHK(hipEventCreate(&b));
+    for (int w = 0; w < 3; w++) hipLaunchKernelGGL((k_read<UNROLL, NT>), dim3(blocks), dim3(256), 0, 0, buf, n_vec, out);
+    CHK(hipDeviceSynchronize());
+    double ms_tot = 0;
+    const int reps = 20;
+    for (int r = 0; r < reps; r++) {
+        CHK(hipEventRecord(a, 0));
+        hipLaunchKernelGGL((k_read<UNROLL, NT>), dim3(blocks), dim3(256), 0, 0, buf, n_vec, out);
+        CHK(hipEventRecord(b, 0));
+        CHK(hipEventSynchronize(b));
+        float ms = 0;
+        CHK(hipEventElapsedTime(&ms, a, b));
+        ms_tot += ms;
+    }
+    std::printf("unroll %d  %-5s blocks %6d : %8.3f ms  %7.1f GB/s\n", UNROLL, NT ? "nt" : "plain", blocks, ms_tot / reps,
+                bytes / (ms_tot / reps * 1e-3) / 1e9);
+    std::fflush(stdout);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const double gib = argc > 1 ? std::atof(argv[1]) : 16.0;
+    const size_t bytes = (size_t)(gib * 1024.0 * 1024.0 * 1024.0) / 4096 * 4096;
+    v4f* buf = nullptr;
+    float* out = nullptr;
+    CHK(hipMalloc(&buf, bytes));
+    CHK(hipMalloc(&out, sizeof(float) * 65536));
+    CHK(hipMemset(buf, 0, bytes));
+    CHK(hipDeviceSynchronize());
+    const size_t n_vec = bytes / 16;
+    std::printf("streaming read of %.2f GB\n", bytes / 1e9);
+    for (int blocks : { 2048, 8192, 32768 }) {
+        if (run<4, false>(buf, n_vec, out, blocks, (double)bytes)) return 1;
+        if (run<4, true>(buf, n_vec, out, blocks, (double)bytes)) return 1;
+        if (run<8, false>(buf, n_vec, out, blocks, (double)bytes)) return 1;
+        if (run<8, true>(buf, n_vec, out, blocks, (double)bytes)) return 1;
+    }
+    (void)hipFree(buf); (void)hipFree(out);
+    return 0;
+}
