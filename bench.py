@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--bins", type=int, default=8)
     ap.add_argument("--rays", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-comm", action="store_true",
+                    help="single rank only: still create the torch process group and the library's RCCL communicator "
+                         "(all-gather of one chunk per pass), to rehearse the multi-GPU code path on a one-GPU box")
     args = ap.parse_args()
 
     import numpy as np
@@ -128,12 +131,14 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback for the hot path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_comm = world > 1 or args.rehearse_comm
+    if use_comm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     def barrier():
-        if world > 1:
+        if use_comm:
             dist.barrier()
 
     sc = scenes.cornell_box(args.patches, S=args.bins)
@@ -143,7 +148,7 @@ def main():
 
     ctx = api.Context(local_rank)
     ctx.set_shard(rank, world)
-    if world > 1:
+    if use_comm:
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             idt.copy_(torch.from_numpy(api.comm_unique_id()))
@@ -162,7 +167,7 @@ def main():
     info = ctx.info()
     asm = torch.tensor([t_asm, info.last_assemble_ms / 1e3, float(info.pairs_traced), info.last_bvh_ms / 1e3],
                        dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_comm:
         mx = asm.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = asm.clone()
@@ -190,7 +195,7 @@ def main():
     ctx.profile(False)
     info = ctx.info()
     tt = torch.tensor([dt, info.sweep_ms_total / max(1, info.sweep_launches)], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_comm:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt, kern_ms = float(tt[0]), float(tt[1])
     resid = ctx.step(0, want_sum=True)
@@ -230,7 +235,7 @@ def main():
             out["formfactors"]["vs_cpu_port"] = out["formfactors"]["value"] / ff_cpu["value"]
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_comm:
         dist.destroy_process_group()
 
 
