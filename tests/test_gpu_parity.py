@@ -449,14 +449,16 @@ def test_grazing_rays_along_a_shallow_bowl(uv50):
     assert np.array_equal(_bits(F), _bits(Fo))
 
 
-@pytest.mark.parametrize("seed,n,scale", [(1, 300, 1.0), (2, 500, 40.0), (3, 200, 1e-3)])
-def test_random_triangle_soup(seed, n, scale, uv50):
+@pytest.mark.parametrize("seed,n,scale,offset", [(1, 300, 1.0, 0.0), (2, 500, 40.0, 0.0), (3, 200, 1e-3, 0.0),
+                                                 (4, 400, 1.0, 700.0), (5, 300, 1.0, -3.0e4), (6, 1500, 5.0, 0.0)])
+def test_random_triangle_soup(seed, n, scale, offset, uv50):
     """general position: intersecting, overlapping, sliver and tiny triangles with arbitrary vertex
-    normals, at three scene scales -- ray counts and F against the brute-force oracle, exact"""
+    normals, at three scene scales, far from the origin (coordinates much larger than the scene), and a
+    denser one -- ray counts and F against the brute-force oracle, exact"""
     rs = np.random.RandomState(seed)
     c0 = rs.random_sample((n, 1, 3)) * 2 - 1
     size = rs.random_sample((n, 1, 1)) ** 3 * 0.6 + 1e-3
-    tri = (c0 + (rs.random_sample((n, 3, 3)) - 0.5) * size) * scale + 0.37 * scale
+    tri = (c0 + (rs.random_sample((n, 3, 3)) - 0.5) * size) * scale + 0.37 * scale + offset * np.array([1.0, -0.4, 0.25])
     tri[::17, 2] = tri[::17, 1] + (tri[::17, 1] - tri[::17, 0]) * 1e-4       # slivers
     v = tri.reshape(-1, 3).astype(np.float32)
     tv = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
