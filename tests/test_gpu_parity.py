@@ -323,11 +323,12 @@ def test_rccl_binding_single_rank(uv50):
     assert np.array_equal(B0, B1) and np.array_equal(R0, R1)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_row_sharded_solver_on_one_gpu(world, uv50):
+@pytest.mark.parametrize("world,S,n", [(2, 8, 700), (3, 8, 700), (3, 9, 700), (4, 3, 2500), (5, 16, 1300)])
+def test_row_sharded_solver_on_one_gpu(world, S, n, uv50):
     """every rank's kernels (rank > 0: row offset, short last shard, chunk placement, local B and
-    material indices) with the exchange staged through the host: identical to the unsharded run"""
-    sc = scenes.cornell_box(700, S=8, fluorescent=True)
+    material indices; the two launches of a multi-rank pass -- own chunk, then the other columns -- on the
+    VALU and the MFMA kernel) with the exchange staged through the host: identical to the unsharded run"""
+    sc = scenes.cornell_box(n, S=S, fluorescent=(S >= 8))
     E = sc.emission(7.0)
     passes = 5
     with _ctx(sc) as c:
