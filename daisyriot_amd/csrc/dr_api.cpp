@@ -35,6 +35,14 @@ int fail(int code, const char* fmt, ...) {
             return fail(e_ == hipErrorOutOfMemory ? DR_ERR_NOMEM : DR_ERR_DEVICE, "%s failed: %s", #x, \
                         hipGetErrorString(e_));                                                     \
     } while (0)
+// a start/stop event pair that is destroyed on every exit path
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t create() { hipError_t e = hipEventCreate(&a); return e != hipSuccess ? e : hipEventCreate(&b); }
+    float ms() const { float t = 0; return hipEventElapsedTime(&t, a, b) == hipSuccess ? t : 0.0f; }
+    ~EventPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
+};
+
 #define CTX(c)                                                         \
     do {                                                               \
         if (!(c)) return fail(DR_ERR_INVALID, "null context");         \
@@ -274,9 +282,19 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
             lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]);
         }
     }
+    // padding of every triangle's gate box: 1e-4 of the largest side of the scene (fp32, as the oracle)
+    const float box_pad = 1e-4f * std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2])) + 1e-30f;
+    // growth of every BVH node box that makes the cheap node test conservative (node_hit_mask, geom_kernels.hip)
+    float diag2 = 0.0f, maxabs = 0.0f;
+    for (int a = 0; a < 3; a++) {
+        const float ext = (hi[a] - lo[a]) + 2.0f * box_pad;
+        diag2 += ext * ext;
+        maxabs = std::max(maxabs, std::max(std::fabs(lo[a]), std::fabs(hi[a])) + box_pad);
+    }
+    if (!(maxabs < 1e15f)) return fail(DR_ERR_INVALID, "scene coordinates up to %g exceed the supported 1e15", (double)maxabs);
+    const float node_pad = 3e-5f * std::sqrt(diag2) + 4e-6f * maxabs;
     HIPCHK(hipStreamSynchronize(c->stream));
-    free_solver(c); free_F(c); free_scene(c);
-    c->N = N; c->V = V; c->Nn = Nn;
+    free_solver(c); free_F(c); free_scene(c);      // c->N stays 0 ("no mesh") until everything below has succeeded
     HIPCHK(hipMalloc(&c->d_vtx, sizeof(float) * 3 * (size_t)V));
     HIPCHK(hipMalloc(&c->d_nrm, sizeof(float) * 3 * (size_t)Nn));
     HIPCHK(hipMalloc(&c->d_tv, sizeof(int) * 3 * (size_t)N));
@@ -290,30 +308,16 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     HIPCHK(hipMemcpyAsync(c->d_nrm, normals, sizeof(float) * 3 * (size_t)Nn, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_tv, tv, sizeof(int) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_tn, tn, sizeof(int) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
-    // padding of every triangle's gate box: 1e-4 of the largest side of the scene (fp32, as the oracle)
-    const float box_pad = 1e-4f * std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2])) + 1e-30f;
     HIPCHK(launch_patch_records(c->stream, N, c->d_vtx, c->d_nrm, c->d_tv, c->d_tn, box_pad, c->d_patch, c->d_tri));
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, c->stream));
-    // growth of every BVH node box that makes the cheap node test conservative (node_hit_mask, geom_kernels.hip)
-    float diag2 = 0.0f, maxabs = 0.0f;
-    for (int a = 0; a < 3; a++) {
-        const float ext = (hi[a] - lo[a]) + 2.0f * box_pad;
-        diag2 += ext * ext;
-        maxabs = std::max(maxabs, std::max(std::fabs(lo[a]), std::fabs(hi[a])) + box_pad);
-    }
-    if (!(maxabs < 1e15f)) return fail(DR_ERR_INVALID, "scene coordinates up to %g exceed the supported 1e15", (double)maxabs);
-    const float node_pad = 3e-5f * std::sqrt(diag2) + 4e-6f * maxabs;
+    EventPair ev;
+    HIPCHK(ev.create());
+    HIPCHK(hipEventRecord(ev.a, c->stream));
     hipError_t be = build_lbvh(c->stream, N, c->d_tri, lo, hi, node_pad, c->d_bvh, c->d_tri_sorted, &c->n_nodes);
-    if (be != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return fail(DR_ERR_DEVICE, "LBVH build failed: %s", hipGetErrorString(be)); }
-    HIPCHK(hipEventRecord(e1, c->stream));
+    if (be != hipSuccess) return fail(DR_ERR_DEVICE, "LBVH build failed: %s", hipGetErrorString(be));
+    HIPCHK(hipEventRecord(ev.b, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    c->last_bvh_ms = ms;
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    c->last_bvh_ms = ev.ms();
+    c->N = N; c->V = V; c->Nn = Nn;
     recompute_shard(c);
     return DR_OK;
 }
@@ -335,10 +339,9 @@ static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int r
         HIPCHK(hipMemcpyAsync(c->d_uv, uv, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(hipMemsetAsync(c->d_counter, 0, 16 * sizeof(unsigned long long), c->stream));
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, c->stream));
+    EventPair ev;
+    HIPCHK(ev.create());
+    HIPCHK(hipEventRecord(ev.a, c->stream));
     if (c->nrows > 0) {
         TileParams p;
         p.N = c->N; p.K = trace ? K : 1; p.rule = rule; p.trace = trace;
@@ -351,13 +354,11 @@ static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int r
         if (const char* dp = getenv("DR_DEBUG_PAIR")) { p.stats = 1; p.dbg_ray = 0; sscanf(dp, "%d,%d,%d", &p.dbg_lo, &p.dbg_hi, &p.dbg_ray); }
         HIPCHK(launch_ff_tiles(c->stream, p));
     }
-    HIPCHK(hipEventRecord(e1, c->stream));
+    HIPCHK(hipEventRecord(ev.b, c->stream));
     unsigned long long cnt[16] = { 0 };
     HIPCHK(hipMemcpyAsync(cnt, c->d_counter, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    c->last_assemble_ms = ms;
+    c->last_assemble_ms = ev.ms();
     c->pairs_traced = cnt[0]; c->stat_visits = cnt[1]; c->stat_leaves = cnt[2];
     if (getenv("DR_DEBUG_PAIR"))
         fprintf(stderr, "[daisyriot] debug pair: live mask after target test %016llx, final %016llx; blocker of the debug ray: patch %lld "
@@ -365,7 +366,6 @@ static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int r
     else if (getenv("DR_TILE_STATS"))
         fprintf(stderr, "[daisyriot] pairs %llu, node visits %llu (%.1f/pair), leaf tests %llu (%.1f/pair)\n", cnt[0], cnt[1],
                 cnt[0] ? (double)cnt[1] / cnt[0] : 0.0, cnt[2], cnt[0] ? (double)cnt[2] / cnt[0] : 0.0);
-    hipEventDestroy(e0); hipEventDestroy(e1);
     c->have_F = true;
     return DR_OK;
 }
