@@ -115,6 +115,12 @@ def main():
                          "(all-gather of one chunk per pass), to rehearse the multi-GPU code path on a one-GPU box")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: libraries that print there on their own (RCCL's version banner at
+    # communicator creation, for one) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -233,7 +239,8 @@ def main():
             out["cpu_baseline_formfactors"] = ff_cpu
             out["cpu_baseline_all_cores"] = allcores
             out["formfactors"]["vs_cpu_port"] = out["formfactors"]["value"] / ff_cpu["value"]
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if use_comm:
         dist.destroy_process_group()

@@ -28,6 +28,8 @@ EXPORTS = [
     "dr_synchronize", "dr_debug_read_bvh", "dr_shard_rows", "dr_residual_offset",
     "dr_comm_manual", "dr_exchange_export", "dr_exchange_import", "dr_debug_read_array",
     "dr_display_patch_colors", "dr_display_vertex_colors",
+    "dr_formfactors_assemble_split", "dr_vis_exchange_bytes", "dr_vis_exchange_export", "dr_vis_exchange_import",
+    "dr_formfactors_assemble_finish",
 ]
 
 
@@ -88,6 +90,11 @@ def load_library(path=None):
     L.dr_exchange_import.argtypes = [vp, i, vp]
     L.dr_shard_rows.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.dr_residual_offset.argtypes = [i, i, i, i]
+    L.dr_formfactors_assemble_split.argtypes = [vp, vp, i, C.c_float, i, i]
+    L.dr_vis_exchange_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.dr_vis_exchange_export.argtypes = [vp, vp]
+    L.dr_vis_exchange_import.argtypes = [vp, i, vp]
+    L.dr_formfactors_assemble_finish.argtypes = [vp]
     L.dr_display_patch_colors.argtypes = [vp, i, vp, vp]
     L.dr_display_vertex_colors.argtypes = [vp, vp, vp, vp, i, vp]
     for name in EXPORTS:
@@ -210,6 +217,26 @@ class Context:
         uv = _f32(uv).reshape(-1, 2)
         self._chk(self.L.dr_formfactors_assemble(self.h, _p(uv), uv.shape[0], C.c_float(eps), int(rule),
                                                  int(bool(keep_visibility))), "dr_formfactors_assemble")
+
+    # multi-rank assembly in steps, for a host that moves the ray-count slots itself
+    def assemble_split(self, uv, eps=ORIGIN_EPS, rule=RULE_INTEGRAND, keep_visibility=False):
+        uv = _f32(uv).reshape(-1, 2)
+        self._chk(self.L.dr_formfactors_assemble_split(self.h, _p(uv), uv.shape[0], C.c_float(eps), int(rule),
+                                                       int(bool(keep_visibility))), "dr_formfactors_assemble_split")
+
+    def vis_exchange_export(self):
+        n = C.c_size_t()
+        self._chk(self.L.dr_vis_exchange_bytes(self.h, C.byref(n)), "dr_vis_exchange_bytes")
+        out = np.empty(n.value, np.uint8)
+        self._chk(self.L.dr_vis_exchange_export(self.h, _p(out)), "dr_vis_exchange_export")
+        return out
+
+    def vis_exchange_import(self, src_rank, chunk):
+        chunk = np.ascontiguousarray(chunk, dtype=np.uint8)
+        self._chk(self.L.dr_vis_exchange_import(self.h, int(src_rank), _p(chunk)), "dr_vis_exchange_import")
+
+    def assemble_finish(self):
+        self._chk(self.L.dr_formfactors_assemble_finish(self.h), "dr_formfactors_assemble_finish")
 
     def integrand_only(self):
         self._chk(self.L.dr_formfactors_integrand_only(self.h), "dr_formfactors_integrand_only")

@@ -69,6 +69,12 @@ struct dr_context {
     bool have_F = false;
     unsigned char* d_vis = nullptr;
     float* d_uv = nullptr;
+    // ray-count exchange of a multi-rank assembly (TileParams::vex): world * tiles_per_rank * nT slots of 64 x 64 bytes
+    unsigned char* d_vex = nullptr;
+    size_t vex_bytes = 0;
+    bool split_pending = false;       // dr_formfactors_assemble_split done, ..._finish still to come
+    int split_K = 0, split_rule = 0;
+    float split_eps = 0;
     unsigned long long* d_counter = nullptr;
     // solver
     int S = 0, n_mat = 0;
@@ -99,6 +105,7 @@ namespace {
 void free_F(dr_context* c) {
     hipFree(c->d_F); c->d_F = nullptr; c->F_floats = 0; c->have_F = false;
     hipFree(c->d_vis); c->d_vis = nullptr;
+    hipFree(c->d_vex); c->d_vex = nullptr; c->vex_bytes = 0; c->split_pending = false;
 }
 void free_solver(dr_context* c) {
     hipFree(c->d_M); hipFree(c->d_E); hipFree(c->d_B); hipFree(c->d_R[0]); hipFree(c->d_R[1]);
@@ -322,23 +329,38 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     return DR_OK;
 }
 
-static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int rule, int keep_vis, int trace) {
+// vx_mode 0: self-sufficient (every pair that touches this rank's rows is traced here); 1 / 2: the two launches of an
+// assembly with ray-count exchange (TileParams); 2 reuses what 1 set up
+static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int rule, int keep_vis, int trace, int vx_mode = 0) {
     CTX(c);
     if (c->N <= 0) return fail(DR_ERR_STATE, "dr_scene_set_mesh has not been called");
-    if (trace && (!uv || K < 1 || K > 254)) return fail(DR_ERR_INVALID, "need 1 <= K <= 254 samples (K=%d)", K);
+    if (trace && vx_mode != 2 && (!uv || K < 1 || K > 254)) return fail(DR_ERR_INVALID, "need 1 <= K <= 254 samples (K=%d)", K);
     if (rule != DR_RULE_INTEGRAND && rule != DR_RULE_RECIPROCITY) return fail(DR_ERR_INVALID, "unknown rule %d", rule);
-    int rc = ensure_F(c);
-    if (rc) return rc;
-    c->have_F = false;
-    if (c->ldF != (size_t)c->N) HIPCHK(hipMemsetAsync(c->d_F, 0, c->F_floats * sizeof(float), c->stream));
-    hipFree(c->d_vis); c->d_vis = nullptr;
-    if (keep_vis && c->nrows > 0) HIPCHK(hipMalloc(&c->d_vis, (size_t)c->nrows * c->N));
-    if (trace) {
-        hipFree(c->d_uv); c->d_uv = nullptr;
-        HIPCHK(hipMalloc(&c->d_uv, sizeof(float) * 2 * (size_t)K));
-        HIPCHK(hipMemcpyAsync(c->d_uv, uv, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, c->stream));
+    const int nT = (c->N + TILE - 1) / TILE, tiles_per_rank = c->rpr / TILE;
+    if (vx_mode != 2) {
+        int rc = ensure_F(c);
+        if (rc) return rc;
+        c->have_F = false;
+        c->split_pending = false;
+        if (c->ldF != (size_t)c->N) HIPCHK(hipMemsetAsync(c->d_F, 0, c->F_floats * sizeof(float), c->stream));
+        hipFree(c->d_vis); c->d_vis = nullptr;
+        if (keep_vis && c->nrows > 0) HIPCHK(hipMalloc(&c->d_vis, (size_t)c->nrows * c->N));
+        if (trace) {
+            hipFree(c->d_uv); c->d_uv = nullptr;
+            HIPCHK(hipMalloc(&c->d_uv, sizeof(float) * 2 * (size_t)K));
+            HIPCHK(hipMemcpyAsync(c->d_uv, uv, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, c->stream));
+        }
+        HIPCHK(hipMemsetAsync(c->d_counter, 0, 16 * sizeof(unsigned long long), c->stream));
+        if (vx_mode == 1) {
+            const size_t need = (size_t)c->world * tiles_per_rank * nT * (TILE * TILE);
+            if (c->vex_bytes != need) {
+                hipFree(c->d_vex); c->d_vex = nullptr; c->vex_bytes = 0;
+                hipError_t e = hipMalloc(&c->d_vex, need);
+                if (e != hipSuccess) { c->d_vex = nullptr; return fail(DR_ERR_NOMEM, "ray-count exchange buffer of %.2f GB: %s", need / 1e9, hipGetErrorString(e)); }
+                c->vex_bytes = need;
+            }
+        }
     }
-    HIPCHK(hipMemsetAsync(c->d_counter, 0, 16 * sizeof(unsigned long long), c->stream));
     EventPair ev;
     HIPCHK(ev.create());
     HIPCHK(hipEventRecord(ev.a, c->stream));
@@ -349,6 +371,7 @@ static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int r
         p.row0 = c->row0; p.nrows = c->nrows; p.n_nodes = c->n_nodes; p.eps = eps; p.ldF = c->ldF;
         p.F = c->d_F; p.vis = c->d_vis; p.patch = c->d_patch; p.tri = c->d_tri; p.tri_sorted = c->d_tri_sorted; p.bvh = c->d_bvh;
         p.uv = c->d_uv; p.pairs_traced = c->d_counter;
+        p.vx_mode = vx_mode; p.vx_rank = c->rank; p.vx_tiles_per_rank = tiles_per_rank; p.vex = c->d_vex;
         p.stats = getenv("DR_TILE_STATS") ? 1 : 0;
         p.dbg_lo = p.dbg_hi = -1;
         if (const char* dp = getenv("DR_DEBUG_PAIR")) { p.stats = 1; p.dbg_ray = 0; sscanf(dp, "%d,%d,%d", &p.dbg_lo, &p.dbg_hi, &p.dbg_ray); }
@@ -358,7 +381,7 @@ static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int r
     unsigned long long cnt[16] = { 0 };
     HIPCHK(hipMemcpyAsync(cnt, c->d_counter, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->last_assemble_ms = ev.ms();
+    c->last_assemble_ms = (vx_mode == 2 ? c->last_assemble_ms : 0.0) + ev.ms();
     c->pairs_traced = cnt[0]; c->stat_visits = cnt[1]; c->stat_leaves = cnt[2];
     if (getenv("DR_DEBUG_PAIR"))
         fprintf(stderr, "[daisyriot] debug pair: live mask after target test %016llx, final %016llx; blocker of the debug ray: patch %lld "
@@ -366,12 +389,70 @@ static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int r
     else if (getenv("DR_TILE_STATS"))
         fprintf(stderr, "[daisyriot] pairs %llu, node visits %llu (%.1f/pair), leaf tests %llu (%.1f/pair)\n", cnt[0], cnt[1],
                 cnt[0] ? (double)cnt[1] / cnt[0] : 0.0, cnt[2], cnt[0] ? (double)cnt[2] / cnt[0] : 0.0);
-    c->have_F = true;
+    if (vx_mode == 1) {
+        c->split_pending = true; c->split_K = K; c->split_rule = rule; c->split_eps = eps;
+    } else {
+        c->split_pending = false;
+        c->have_F = true;
+        if (vx_mode == 2) { hipFree(c->d_vex); c->d_vex = nullptr; c->vex_bytes = 0; }      // N*N bytes: not kept
+    }
     return DR_OK;
 }
 
 int dr_formfactors_assemble(dr_context* c, const float* uv, int K, float eps, int rule, int keep_vis) {
+    if (!c) return fail(DR_ERR_INVALID, "null context");
+    // several ranks joined by RCCL: every pair between two ranks' rows is traced by one of them only and its 64 x 64
+    // ray counts are exchanged (one all-gather of the slot buffers); otherwise the rank is self-sufficient
+    // (DR_VIS_EXCHANGE_REHEARSE: take this path with a single-rank communicator too -- a one-GPU rehearsal of the calls)
+    if ((c->world > 1 || getenv("DR_VIS_EXCHANGE_REHEARSE")) && c->comm.comm && !getenv("DR_NO_VIS_EXCHANGE")) {
+        int rc = assemble_impl(c, uv, K, eps, rule, keep_vis, 1, 1);
+        if (rc) return rc;
+        const size_t chunk = c->vex_bytes / (size_t)c->world;
+        std::string err = comm_allgather_bytes_inplace(c->comm, c->d_vex, chunk, c->stream);
+        if (!err.empty()) return fail(DR_ERR_COMM, "%s", err.c_str());
+        return assemble_impl(c, nullptr, c->split_K, c->split_eps, c->split_rule, 0, 1, 2);
+    }
     return assemble_impl(c, uv, K, eps, rule, keep_vis, 1);
+}
+
+/* the same in three steps for a host that moves the slot buffers itself (tests, MPI staging) */
+int dr_formfactors_assemble_split(dr_context* c, const float* uv, int K, float eps, int rule, int keep_vis) {
+    if (!c) return fail(DR_ERR_INVALID, "null context");
+    return assemble_impl(c, uv, K, eps, rule, keep_vis, 1, 1);
+}
+
+int dr_vis_exchange_bytes(dr_context* c, size_t* chunk_bytes) {
+    CTX(c);
+    if (!chunk_bytes) return fail(DR_ERR_INVALID, "chunk_bytes is null");
+    if (!c->split_pending) return fail(DR_ERR_STATE, "dr_formfactors_assemble_split has not been called");
+    *chunk_bytes = c->vex_bytes / (size_t)c->world;
+    return DR_OK;
+}
+
+int dr_vis_exchange_export(dr_context* c, void* out) {
+    CTX(c);
+    if (!out) return fail(DR_ERR_INVALID, "out is null");
+    if (!c->split_pending) return fail(DR_ERR_STATE, "dr_formfactors_assemble_split has not been called");
+    const size_t chunk = c->vex_bytes / (size_t)c->world;
+    HIPCHK(hipMemcpyAsync(out, c->d_vex + (size_t)c->rank * chunk, chunk, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DR_OK;
+}
+
+int dr_vis_exchange_import(dr_context* c, int src_rank, const void* in) {
+    CTX(c);
+    if (!in || src_rank < 0 || src_rank >= c->world) return fail(DR_ERR_INVALID, "bad source rank %d", src_rank);
+    if (!c->split_pending) return fail(DR_ERR_STATE, "dr_formfactors_assemble_split has not been called");
+    const size_t chunk = c->vex_bytes / (size_t)c->world;
+    HIPCHK(hipMemcpyAsync(c->d_vex + (size_t)src_rank * chunk, in, chunk, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DR_OK;
+}
+
+int dr_formfactors_assemble_finish(dr_context* c) {
+    if (!c) return fail(DR_ERR_INVALID, "null context");
+    if (!c->split_pending) return fail(DR_ERR_STATE, "dr_formfactors_assemble_split has not been called");
+    return assemble_impl(c, nullptr, c->split_K, c->split_eps, c->split_rule, 0, 1, 2);
 }
 int dr_formfactors_integrand_only(dr_context* c) {
     return assemble_impl(c, nullptr, 1, 0.0f, DR_RULE_INTEGRAND, 0, 0);

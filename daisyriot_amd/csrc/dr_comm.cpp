@@ -90,6 +90,15 @@ std::string comm_allgather_inplace(Comm& c, float* buf, size_t count, hipStream_
     return "";
 }
 
+std::string comm_allgather_bytes_inplace(Comm& c, unsigned char* buf, size_t bytes_per_rank, hipStream_t st) {
+    Api& a = api();
+    if (!c.comm) return "communicator not initialised";
+    const int ncclInt8 = 0;
+    int rc = a.allgather(buf + (size_t)c.rank * bytes_per_rank, buf, bytes_per_rank, ncclInt8, c.comm, st);
+    if (rc) return nccl_err("ncclAllGather", rc);
+    return "";
+}
+
 void comm_destroy(Comm& c) {
     if (c.comm) { api().destroy(c.comm); c.comm = nullptr; }
 }

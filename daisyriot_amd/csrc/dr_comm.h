@@ -17,6 +17,8 @@ std::string comm_unique_id(void* out128);
 std::string comm_init(Comm& c, const void* id128, int rank, int world);
 // in-place all-gather of `count` floats per rank inside buf (rank r's chunk at r*count)
 std::string comm_allgather_inplace(Comm& c, float* buf, size_t count, hipStream_t st);
+// the same for bytes (the ray-count slots of a multi-rank assembly)
+std::string comm_allgather_bytes_inplace(Comm& c, unsigned char* buf, size_t bytes_per_rank, hipStream_t st);
 void comm_destroy(Comm& c);
 
 }  // namespace dr

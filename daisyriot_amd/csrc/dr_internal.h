@@ -60,6 +60,14 @@ struct TileParams {
     int stats;                          // count [1],[2] too (debug; costs two atomics per pair)
     int dbg_ray;
     int dbg_lo, dbg_hi;                 // STATS build: [3] = final live-ray mask of this pair, [1] = mask after the target test
+    // Ray-count exchange between ranks (multi-rank assembly without tracing a pair twice).  A tile pair {o, t} with
+    // o in this rank's rows and t in rank B's is traced by exactly one of the two: by the lower rank when o + t is even,
+    // by the higher rank when it is odd.  vx_mode 0: no exchange, every rank traces all pairs that touch its rows.
+    // vx_mode 1 (first launch): own x own pairs as always; foreign pairs only when they are this rank's, and their
+    // 64 x 64 ray counts also go to slot (o, t) of `vex`.  vx_mode 2 (second launch, after the slots of all ranks
+    // were gathered): the foreign pairs the other side traced: counts from slot (t, o), F tile written from them.
+    int vx_mode, vx_rank, vx_tiles_per_rank;
+    unsigned char* vex;                 // [world * tiles_per_rank][nT][64*64] ray counts, row = tile of the min index
 };
 
 struct SweepParams {

@@ -574,6 +574,17 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
     const int o = P.tile0 + blockIdx.y;
     const bool t_owned = (t >= P.tile0) && (t < P.tile0 + P.nOwnedTiles);
     if (t_owned && t < o) return;   // the unordered tile pair {t,o} belongs to block (x=o, y=t-tile0)
+    // ray-count exchange (TileParams): who traces a pair with a foreign tile, and what the second launch covers
+    bool from_slot = false;
+    if (P.vx_mode != 0) {
+        if (t_owned) {
+            if (P.vx_mode == 2) return;                    // own x own pairs were finished by the first launch
+        } else {
+            const bool mine = (((t + o) & 1) == 0) == (P.vx_rank < t / P.vx_tiles_per_rank);
+            if (mine != (P.vx_mode == 1)) return;
+            from_slot = (P.vx_mode == 2);
+        }
+    }
     const int bi = min(t, o), bj = max(t, o);
     const int I0 = bi * TILE, J0 = bj * TILE;
     const bool diag = (bi == bj);
@@ -597,8 +608,13 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
     }
     __syncthreads();
 
+    if (from_slot) {
+        // the other rank traced this pair: its counts, in the same orientation (rows = the tile of the lower index)
+        const unsigned char* slot = P.vex + ((size_t)t * P.nT + o) * (TILE * TILE);
+        for (int p = tid; p < TILE * TILE; p += NT) sVis[p >> 6][p & 63] = slot[p];
+    }
     // ---- which pairs are traced: stored integrand lo->hi > 0 (vs/OptixPrimeFunctionality.cpp:190)
-    for (int p0 = 0; p0 < TILE * TILE; p0 += NT) {
+    for (int p0 = 0; p0 < (from_slot ? 0 : TILE * TILE); p0 += NT) {
         const int p = p0 + tid;
         const int i = p >> 6, j = p & 63;
         const int gi = I0 + i, gj = J0 + j;
@@ -669,6 +685,11 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
     }
     __syncthreads();
     if (tid == 0 && n_act > 0 && P.trace && P.pairs_traced) atomicAdd(P.pairs_traced, (unsigned long long)n_act);
+    if (P.vx_mode == 1 && !t_owned) {
+        // this pair is also the other rank's: hand its ray counts over (slot of own tile o, foreign tile t)
+        unsigned char* slot = P.vex + ((size_t)o * P.nT + t) * (TILE * TILE);
+        for (int p = tid; p < TILE * TILE; p += NT) slot[p] = sVis[p >> 6][p & 63];
+    }
 
     // ---- write both F tiles once, coalesced (the integrand is recomputed rather than kept in LDS)
     const float Kf = (float)P.K;

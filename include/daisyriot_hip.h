@@ -97,6 +97,20 @@ int dr_scene_set_mesh(dr_context* ctx, const float* vertices, int V,
 int dr_formfactors_assemble(dr_context* ctx, const float* uv, int K,
                             float origin_eps, int rule, int keep_visibility);
 
+/* Multi-rank assembly (no reference counterpart: the reference is single-GPU).  A pair of patches in
+ * two ranks' rows is needed by both (F[i][j] and F[j][i] share the ray count); with an RCCL
+ * communicator dr_formfactors_assemble traces it on one of the two ranks only and all-gathers the
+ * 64 x 64-byte ray-count slots of the tile pairs.  Without one (DR_NO_COMM timing runs, a single rank of a
+ * shard on its own) every rank traces all pairs that touch its rows.  A host that moves buffers itself
+ * does the same in steps: ..._split on every rank, then every rank's export chunk
+ * (dr_vis_exchange_bytes bytes) imported into every other rank, then ..._finish on every rank. */
+int dr_formfactors_assemble_split(dr_context* ctx, const float* uv, int K,
+                                  float origin_eps, int rule, int keep_visibility);
+int dr_vis_exchange_bytes(dr_context* ctx, size_t* chunk_bytes);
+int dr_vis_exchange_export(dr_context* ctx, void* chunk_out);
+int dr_vis_exchange_import(dr_context* ctx, int src_rank, const void* chunk_in);
+int dr_formfactors_assemble_finish(dr_context* ctx);
+
 /* Unoccluded integrand only (parallellism::calculateRow, vs/parallellism.cu:91-111):
  * F = stored integrand, no rays.  For tests and timing of the integrand alone. */
 int dr_formfactors_integrand_only(dr_context* ctx);

@@ -557,3 +557,48 @@ def test_c5_shard_256k_fluorescent(uv50):
         assert (np.abs(B1[r:r + 48] - Bo) / (np.abs(Bo).max(axis=0) + 1e-30)).max() < 2e-5
         own = c.exchange_export().reshape(8, rpr)           # this rank's new residual chunk, bin-major
         assert (np.abs(own[:, 30000:30048].T - Ro) / (np.abs(Ro).max(axis=0) + 1e-30)).max() < 2e-5
+
+
+@pytest.mark.parametrize("world,n,rule", [(2, 700, api.RULE_INTEGRAND), (3, 1000, api.RULE_RECIPROCITY), (5, 1500, api.RULE_INTEGRAND)])
+def test_multi_rank_assembly_with_ray_count_exchange(world, n, rule, uv50):
+    """a pair between two ranks' rows is traced by one of them only and its ray counts handed over (what
+    dr_formfactors_assemble does over RCCL, here with the slot buffers staged through the host): every rank ends
+    with exactly its rows of the single-GPU matrix, and together the ranks trace every pair once"""
+    sc = scenes.cornell_box(n, S=3)
+    with _ctx(sc) as c:
+        c.assemble(uv50, rule=rule, keep_visibility=True)
+        F, V = c.read_rows(0, sc.N), c.read_visibility(0, sc.N)
+        traced_once = c.info().pairs_traced
+    ranks = []
+    for r in range(world):
+        c = api.Context(0)
+        c.set_shard(r, world)
+        c.comm_manual()
+        c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+        c.assemble_split(uv50, rule=rule, keep_visibility=True)
+        ranks.append(c)
+    total = sum(c.info().pairs_traced for c in ranks)
+    assert total == traced_once                                    # nothing traced twice, nothing left out
+    chunks = [c.vis_exchange_export() for c in ranks]
+    for d, c in enumerate(ranks):
+        for s_, ch in enumerate(chunks):
+            if s_ != d:
+                c.vis_exchange_import(s_, ch)
+        c.assemble_finish()
+    for c in ranks:
+        row0, nrows, _ = c.shard()
+        if nrows:
+            assert np.array_equal(c.read_visibility(row0, nrows), V[row0:row0 + nrows])
+            assert np.array_equal(_bits(c.read_rows(row0, nrows)), _bits(F[row0:row0 + nrows]))
+        c.close()
+    # a rank on its own (no exchange) still gets its rows: every pair that touches them is traced locally
+    with api.Context(0) as c:
+        c.set_shard(world - 1, world)
+        c.comm_manual()
+        c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+        c.assemble(uv50, rule=rule)
+        row0, nrows, _ = c.shard()
+        if nrows:
+            assert np.array_equal(_bits(c.read_rows(row0, nrows)), _bits(F[row0:row0 + nrows]))
+        with pytest.raises(api.DaisyRiotError):
+            c.assemble_finish()                                    # nothing pending
