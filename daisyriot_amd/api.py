@@ -29,7 +29,7 @@ EXPORTS = [
     "dr_comm_manual", "dr_exchange_export", "dr_exchange_import", "dr_debug_read_array",
     "dr_display_patch_colors", "dr_display_vertex_colors",
     "dr_formfactors_assemble_split", "dr_vis_exchange_bytes", "dr_vis_exchange_export", "dr_vis_exchange_import",
-    "dr_formfactors_assemble_finish",
+    "dr_formfactors_assemble_finish", "dr_vis_exchange_tracer",
 ]
 
 
@@ -95,6 +95,7 @@ def load_library(path=None):
     L.dr_vis_exchange_export.argtypes = [vp, vp]
     L.dr_vis_exchange_import.argtypes = [vp, i, vp]
     L.dr_formfactors_assemble_finish.argtypes = [vp]
+    L.dr_vis_exchange_tracer.argtypes = [i, i, i, i]
     L.dr_display_patch_colors.argtypes = [vp, i, vp, vp]
     L.dr_display_vertex_colors.argtypes = [vp, vp, vp, vp, i, vp]
     for name in EXPORTS:
@@ -124,6 +125,11 @@ def shard_rows(N, rank, world):
     if L.dr_shard_rows(int(N), int(rank), int(world), C.byref(a), C.byref(b), C.byref(c)):
         raise DaisyRiotError("dr_shard_rows: %s" % L.dr_last_error().decode())
     return a.value, b.value, c.value
+
+
+def vis_exchange_tracer(N, world, patch_a, patch_b):
+    """rank that traces the pair of patches (a, b) in a world-way assembly -- pure host arithmetic of the library"""
+    return int(load_library().dr_vis_exchange_tracer(int(N), int(world), int(patch_a), int(patch_b)))
 
 
 def residual_offset(i, s, S, rows_per_rank):

@@ -259,6 +259,15 @@ int dr_shard_rows(int N, int rank, int world, int* row0, int* nrows, int* rpr) {
     return DR_OK;
 }
 
+int dr_vis_exchange_tracer(int N, int world, int patch_a, int patch_b) {
+    if (N < 1 || world < 1 || patch_a < 0 || patch_b < 0 || patch_a >= N || patch_b >= N) return -1;
+    int row0, nrows, rpr;
+    shard_rows(N, 0, world, &row0, &nrows, &rpr);
+    const int ta = patch_a / TILE, tb = patch_b / TILE, T = rpr / TILE;
+    if (ta / T == tb / T) return ta / T;           // both in one rank's rows: that rank
+    return vx_tracer_rank(ta, tb, T);
+}
+
 size_t dr_residual_offset(int i, int s, int S, int rpr) {
     // chunk-major (one chunk per rank), bin-major inside a chunk: see sweep_kernels.hip
     return ((size_t)(i / rpr) * S + s) * rpr + (size_t)(i % rpr);

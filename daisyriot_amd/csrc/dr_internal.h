@@ -70,6 +70,15 @@ struct TileParams {
     unsigned char* vex;                 // [world * tiles_per_rank][nT][64*64] ray counts, row = tile of the min index
 };
 
+// Which rank traces the tile pair {a, b} whose tiles lie in two different ranks' rows (tiles_per_rank tiles of 64 rows
+// each per rank): the rank of the lower tile when a + b is even, the rank of the higher tile when it is odd -- every
+// rank gets half of the pairs it shares with each other rank.  One definition for the kernel and the host.
+__host__ __device__ inline int vx_tracer_rank(int a, int b, int tiles_per_rank) {
+    const int ra = a / tiles_per_rank, rb = b / tiles_per_rank;
+    const int lo = ra < rb ? ra : rb, hi = ra < rb ? rb : ra;
+    return (((a + b) & 1) == 0) ? lo : hi;
+}
+
 struct SweepParams {
     int N;            // patches (columns with data)
     int S;

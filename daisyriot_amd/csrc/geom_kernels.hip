@@ -580,7 +580,7 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
         if (t_owned) {
             if (P.vx_mode == 2) return;                    // own x own pairs were finished by the first launch
         } else {
-            const bool mine = (((t + o) & 1) == 0) == (P.vx_rank < t / P.vx_tiles_per_rank);
+            const bool mine = vx_tracer_rank(o, t, P.vx_tiles_per_rank) == P.vx_rank;
             if (mine != (P.vx_mode == 1)) return;
             from_slot = (P.vx_mode == 2);
         }

@@ -104,6 +104,8 @@ int dr_formfactors_assemble(dr_context* ctx, const float* uv, int K,
  * shard on its own) every rank traces all pairs that touch its rows.  A host that moves buffers itself
  * does the same in steps: ..._split on every rank, then every rank's export chunk
  * (dr_vis_exchange_bytes bytes) imported into every other rank, then ..._finish on every rank. */
+/* pure host arithmetic: the rank that traces the pair of patches (a, b) in a `world`-way assembly (-1: bad argument) */
+int dr_vis_exchange_tracer(int N, int world, int patch_a, int patch_b);
 int dr_formfactors_assemble_split(dr_context* ctx, const float* uv, int K,
                                   float origin_eps, int rule, int keep_visibility);
 int dr_vis_exchange_bytes(dr_context* ctx, size_t* chunk_bytes);

@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 from daisyriot_amd import api
@@ -65,3 +67,25 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
                 assert "liboracle" not in text and "oracle.h" not in text, f
     assert "oracle" not in open(os.path.join(pkg, "csrc", "Makefile")).read().replace("the oracle", "")
+
+
+def test_ray_count_exchange_assignment_is_a_balanced_partition():
+    """multi-rank assembly: every pair of patches is traced by exactly one rank, one of the two that need it, and
+    every rank gets its share (host mirror of the rule the tile kernel applies; pure arithmetic, no GPU)"""
+    N, world = 65536, 8
+    rs = np.random.RandomState(0)
+    a, b = rs.randint(0, N, 4000), rs.randint(0, N, 4000)
+    row0, nrows, rpr = api.shard_rows(N, 0, world)
+    ra, rb = a // rpr, b // rpr
+    tr = np.array([api.vis_exchange_tracer(N, world, x, y) for x, y in zip(a, b)])
+    assert np.all((tr == ra) | (tr == rb))                              # one of the two owners
+    assert np.all(tr == np.array([api.vis_exchange_tracer(N, world, y, x) for x, y in zip(a, b)]))     # symmetric
+    same = ra == rb
+    assert np.all(tr[same] == ra[same])
+    # balance over all tile pairs of two different ranks: each side traces exactly half
+    T = rpr // 64
+    for r1, r2 in ((0, 1), (2, 7), (3, 4)):
+        t1, t2 = np.meshgrid(np.arange(r1 * T, (r1 + 1) * T), np.arange(r2 * T, (r2 + 1) * T), indexing="ij")
+        who = np.array([api.vis_exchange_tracer(N, world, int(x) * 64, int(y) * 64) for x, y in zip(t1.ravel()[::7], t2.ravel()[::7])])
+        assert abs((who == r1).mean() - 0.5) < 0.02 and set(who.tolist()) == {r1, r2}
+    assert api.vis_exchange_tracer(N, world, -1, 0) == -1 and api.vis_exchange_tracer(N, world, 0, N) == -1
