@@ -413,7 +413,19 @@ int dr_formfactors_assemble(dr_context* c, const float* uv, int K, float eps, in
     // several ranks joined by RCCL: every pair between two ranks' rows is traced by one of them only and its 64 x 64
     // ray counts are exchanged (one all-gather of the slot buffers); otherwise the rank is self-sufficient
     // (DR_VIS_EXCHANGE_REHEARSE: take this path with a single-rank communicator too -- a one-GPU rehearsal of the calls)
-    if ((c->world > 1 || getenv("DR_VIS_EXCHANGE_REHEARSE")) && c->comm.comm && !getenv("DR_NO_VIS_EXCHANGE")) {
+    bool exchange = (c->world > 1 || getenv("DR_VIS_EXCHANGE_REHEARSE")) && c->comm.comm && !getenv("DR_NO_VIS_EXCHANGE");
+    if (exchange) {
+        // the slot buffer is N*N bytes on every rank; when it does not fit beside the F shard every rank traces for
+        // itself.  Decided from the card's TOTAL memory, so that all ranks of a homogeneous node decide alike.
+        HIPCHK(hipSetDevice(c->device));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, c->device));
+        const int nT = (c->N + TILE - 1) / TILE;
+        const double need = (double)c->world * (c->rpr / TILE) * nT * (TILE * TILE) + 4.0 * std::max(c->nrows, 1) * (double)c->ldF +
+                            (keep_vis ? (double)c->nrows * c->N : 0.0);
+        if (need > 0.85 * (double)prop.totalGlobalMem) exchange = false;
+    }
+    if (exchange) {
         int rc = assemble_impl(c, uv, K, eps, rule, keep_vis, 1, 1);
         if (rc) return rc;
         const size_t chunk = c->vex_bytes / (size_t)c->world;
