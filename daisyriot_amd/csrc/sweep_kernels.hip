@@ -403,8 +403,14 @@ static hipError_t launch_sweep_mfma(hipStream_t st, const SweepParams& p) {
 hipError_t launch_sweep(hipStream_t st, const SweepParams& p_in) {
     if (p_in.nrows <= 0) return hipSuccess;
     SweepParams p = p_in;
-    static int skew = -1, mfma = -1;
-    if (skew < 0) { const char* e = getenv("DR_SWEEP_SKEW"); skew = e ? atoi(e) : 37; }
+    // Start tile of a block = blockIdx.x * skew (mod tiles).  While the gathered residual fits a slice of L2
+    // (4 MiB per XCD) a skew decorrelates the blocks' column positions, worth +0.5 % at N = 65 536; once it does
+    // not (N = 131 072, S = 8: 4 MiB), blocks that run through the columns in step keep the few residual tiles
+    // they are all reading in L2: 37 -> 0 is +8 % there and +14 % at N = 262 144 (profiles/r01/sweep_shards.md).
+    static int skew_env = -2, mfma = -1;
+    if (skew_env == -2) { const char* e = getenv("DR_SWEEP_SKEW"); skew_env = e ? atoi(e) : -1; }
+    const size_t residual_bytes = sizeof(float) * (size_t)p.world * p.rpr * p.S;
+    const int skew = skew_env >= 0 ? skew_env : (residual_bytes <= ((size_t)5 << 19) ? 37 : 0);
     if (mfma < 0) { const char* e = getenv("DR_SWEEP_MFMA"); mfma = e ? atoi(e) : 1; }
     p.skew = skew;
     if (p.S > 8 && mfma) return launch_sweep_mfma(st, p);
