@@ -27,7 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BARE_READ_GBS = 7072.0     # what a kernel that only reads 17.18 GB reaches on this part (tools/hbm_probe.hip, profiles/r01/hbm_probe.md)
+BARE_READ_GBS = 7215.0     # the best a kernel that only reads 17.18 GB reaches on this part (tools/hbm_probe.hip, profiles/r01/hbm_probe.md)
 
 
 def sweep_bytes(nrows, N, S, n_mat):

@@ -28,6 +28,24 @@ __global__ __launch_bounds__(256) void k_read(const v4f* __restrict__ src, size_
     if (s == 12345.678f) out[blockIdx.x] = s;       // keeps the loads alive; practically never true
 }
 
+// each block reads one contiguous segment (the way a block of the light pass walks along its rows)
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void k_read_seg(const v4f* __restrict__ src, size_t n_vec, float* __restrict__ out) {
+    const size_t per_block = n_vec / gridDim.x;
+    const v4f* p = src + (size_t)blockIdx.x * per_block;
+    v4f acc = { 0, 0, 0, 0 };
+    size_t i = threadIdx.x;
+    for (; i + (UNROLL - 1) * 256 < per_block; i += UNROLL * 256) {
+        v4f v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) v[u] = NT ? __builtin_nontemporal_load(p + i + u * 256) : p[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) acc += v[u];
+    }
+    float s = acc[0] + acc[1] + acc[2] + acc[3];
+    if (s == 12345.678f) out[blockIdx.x] = s;
+}
+
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <int UNROLL, bool NT>
@@ -54,6 +72,30 @@ int run(const v4f* buf, size_t n_vec, float* out, int blocks, double bytes) {
     return 0;
 }
 
+template <int UNROLL, bool NT>
+int run_seg(const v4f* buf, size_t n_vec, float* out, int blocks, double bytes) {
+    hipEvent_t a, b;
+    CHK(hipEventCreate(&a));
+    CHK(hipEventCreate(&b));
+    for (int w = 0; w < 3; w++) hipLaunchKernelGGL((k_read_seg<UNROLL, NT>), dim3(blocks), dim3(256), 0, 0, buf, n_vec, out);
+    CHK(hipDeviceSynchronize());
+    double ms_tot = 0;
+    const int reps = 20;
+    for (int r = 0; r < reps; r++) {
+        CHK(hipEventRecord(a, 0));
+        hipLaunchKernelGGL((k_read_seg<UNROLL, NT>), dim3(blocks), dim3(256), 0, 0, buf, n_vec, out);
+        CHK(hipEventRecord(b, 0));
+        CHK(hipEventSynchronize(b));
+        float ms = 0;
+        CHK(hipEventElapsedTime(&ms, a, b));
+        ms_tot += ms;
+    }
+    std::printf("segments unroll %d  %-5s blocks %6d : %8.3f ms  %7.1f GB/s\n", UNROLL, NT ? "nt" : "plain", blocks, ms_tot / reps,
+                bytes / (ms_tot / reps * 1e-3) / 1e9);
+    std::fflush(stdout);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const double gib = argc > 1 ? std::atof(argv[1]) : 16.0;
     const size_t bytes = (size_t)(gib * 1024.0 * 1024.0 * 1024.0) / 4096 * 4096;
@@ -70,6 +112,14 @@ int main(int argc, char** argv) {
         if (run<4, true>(buf, n_vec, out, blocks, (double)bytes)) return 1;
         if (run<8, false>(buf, n_vec, out, blocks, (double)bytes)) return 1;
         if (run<8, true>(buf, n_vec, out, blocks, (double)bytes)) return 1;
+    }
+    for (int blocks : { 131072, 524288 }) {
+        if (run<4, true>(buf, n_vec, out, blocks, (double)bytes)) return 1;
+        if (run<2, true>(buf, n_vec, out, blocks, (double)bytes)) return 1;
+    }
+    for (int blocks : { 512, 1024, 2048, 8192, 65536 }) {
+        if (run_seg<4, true>(buf, n_vec, out, blocks, (double)bytes)) return 1;
+        if (run_seg<8, true>(buf, n_vec, out, blocks, (double)bytes)) return 1;
     }
     (void)hipFree(buf); (void)hipFree(out);
     return 0;
