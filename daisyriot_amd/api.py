@@ -29,7 +29,7 @@ EXPORTS = [
     "dr_comm_manual", "dr_exchange_export", "dr_exchange_import", "dr_debug_read_array",
     "dr_display_patch_colors", "dr_display_vertex_colors",
     "dr_formfactors_assemble_split", "dr_vis_exchange_bytes", "dr_vis_exchange_export", "dr_vis_exchange_import",
-    "dr_formfactors_assemble_finish", "dr_vis_exchange_tracer",
+    "dr_formfactors_assemble_finish", "dr_vis_exchange_tracer", "dr_solver_skip_zero_blocks",
 ]
 
 
@@ -42,7 +42,7 @@ class Info(C.Structure):
                 ("nrows", C.c_int), ("rows_per_rank", C.c_int), ("n_bvh_nodes", C.c_int),
                 ("ld_F", C.c_size_t), ("bytes_F", C.c_size_t), ("last_assemble_ms", C.c_double),
                 ("last_bvh_ms", C.c_double), ("pairs_traced", C.c_uint64), ("sweep_launches", C.c_uint64),
-                ("sweep_ms_total", C.c_double)]
+                ("sweep_ms_total", C.c_double), ("blocks_nonzero", C.c_uint64), ("blocks_total", C.c_uint64)]
 
 
 _lib = None
@@ -96,6 +96,7 @@ def load_library(path=None):
     L.dr_vis_exchange_import.argtypes = [vp, i, vp]
     L.dr_formfactors_assemble_finish.argtypes = [vp]
     L.dr_vis_exchange_tracer.argtypes = [i, i, i, i]
+    L.dr_solver_skip_zero_blocks.argtypes = [vp, i]
     L.dr_display_patch_colors.argtypes = [vp, i, vp, vp]
     L.dr_display_vertex_colors.argtypes = [vp, vp, vp, vp, i, vp]
     for name in EXPORTS:
@@ -297,6 +298,10 @@ class Context:
         r = np.zeros((self.N, self.S), np.float32) if R else None
         self._chk(self.L.dr_solver_read(self.h, _p(b) if B else None, _p(r) if R else None), "dr_solver_read")
         return b, r
+
+    def skip_zero_blocks(self, enable=True):
+        """light passes skip the 32 x 256 blocks of F that are entirely zero (off by default; results are bit-identical)"""
+        self._chk(self.L.dr_solver_skip_zero_blocks(self.h, int(bool(enable))), "dr_solver_skip_zero_blocks")
 
     def residual_sums(self):
         s = np.zeros(MAX_BINS, np.float64)

@@ -82,6 +82,11 @@ struct dr_context {
     int* d_mat = nullptr;
     double* d_sums = nullptr;
     float* d_Gpart = nullptr;
+    // optional zero-block skipping of the light pass (dr_solver_skip_zero_blocks)
+    bool skip_zero = false, mask_valid = false;
+    unsigned* d_mask = nullptr;
+    int mask_words = 0;
+    unsigned long long blocks_nonzero = 0, blocks_total = 0;
     float* d_stage = nullptr;     // N x S staging for layout conversion on read-back
     float* d_rgb = nullptr;       // display colours of the local rows (nrows x 3), valid after dr_display_patch_colors
     bool have_rgb = false;
@@ -106,6 +111,7 @@ void free_F(dr_context* c) {
     hipFree(c->d_F); c->d_F = nullptr; c->F_floats = 0; c->have_F = false;
     hipFree(c->d_vis); c->d_vis = nullptr;
     hipFree(c->d_vex); c->d_vex = nullptr; c->vex_bytes = 0; c->split_pending = false;
+    hipFree(c->d_mask); c->d_mask = nullptr; c->mask_valid = false; c->mask_words = 0;
 }
 void free_solver(dr_context* c) {
     hipFree(c->d_M); hipFree(c->d_E); hipFree(c->d_B); hipFree(c->d_R[0]); hipFree(c->d_R[1]);
@@ -160,12 +166,39 @@ void drain_events(dr_context* c) {
     c->ev_used = 0;
 }
 
+// one bit per 32-row x 256-column block of the F shard (SweepParams::tile_mask); counts them for dr_get_info
+int build_tile_mask(dr_context* c) {
+    const int row_blocks = (std::max(c->nrows, 1) + 31) / 32;
+    const int words = (int)((c->ldF / 256 + 31) / 32);
+    if (!c->d_mask || c->mask_words != words) {
+        hipFree(c->d_mask); c->d_mask = nullptr;
+        HIPCHK(hipMalloc(&c->d_mask, sizeof(unsigned) * (size_t)row_blocks * words));
+        c->mask_words = words;
+    }
+    HIPCHK(hipMemsetAsync(c->d_mask, 0, sizeof(unsigned) * (size_t)row_blocks * words, c->stream));
+    HIPCHK(launch_tile_mask(c->stream, c->d_F, c->nrows, c->ldF, c->d_mask, words));
+    std::vector<unsigned> h((size_t)row_blocks * words);
+    HIPCHK(hipMemcpyAsync(h.data(), c->d_mask, sizeof(unsigned) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    unsigned long long nz = 0;
+    for (unsigned w : h) nz += (unsigned long long)__builtin_popcount(w);
+    c->blocks_nonzero = nz;
+    c->blocks_total = (unsigned long long)((c->nrows + 31) / 32) * (c->ldF / 256);
+    c->mask_valid = true;
+    return DR_OK;
+}
+
 int sweep_once(dr_context* c) {
     SweepParams p;
     p.N = c->N; p.S = c->S; p.rpr = c->rpr; p.world = c->world; p.row0 = c->row0; p.nrows = c->nrows;
     p.ldF = c->ldF; p.F = c->d_F; p.Rin = c->d_R[c->cur]; p.Rout = c->d_R[c->cur ^ 1]; p.rank = c->rank;
     p.B = c->d_B; p.M = c->d_M; p.mat = c->d_mat; p.n_mat = c->n_mat;
     p.skew = 0; p.ksplit = c->ksplit; p.Gpart = c->d_Gpart;
+    p.tile_mask = nullptr; p.mask_words = 0;
+    if (c->skip_zero) {
+        if (!c->mask_valid) { int rc = build_tile_mask(c); if (rc) return rc; }
+        p.tile_mask = c->d_mask; p.mask_words = c->mask_words;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profile) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -350,6 +383,7 @@ static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int r
         int rc = ensure_F(c);
         if (rc) return rc;
         c->have_F = false;
+        c->mask_valid = false;
         c->split_pending = false;
         if (c->ldF != (size_t)c->N) HIPCHK(hipMemsetAsync(c->d_F, 0, c->F_floats * sizeof(float), c->stream));
         hipFree(c->d_vis); c->d_vis = nullptr;
@@ -403,6 +437,7 @@ static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int r
     } else {
         c->split_pending = false;
         c->have_F = true;
+        c->mask_valid = false;
         if (vx_mode == 2) { hipFree(c->d_vex); c->d_vex = nullptr; c->vex_bytes = 0; }      // N*N bytes: not kept
     }
     return DR_OK;
@@ -525,6 +560,7 @@ int dr_formfactors_load_rows(dr_context* c, int row0, int nrows, const float* F)
                                 sizeof(float) * c->N, nrows, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->have_F = true;
+    c->mask_valid = false;
     return DR_OK;
 }
 
@@ -597,6 +633,12 @@ int dr_solver_step(dr_context* c, int n_passes, float* residual_sum_out) {
         for (int s = 0; s < c->S; s++) t += sums[s];
         *residual_sum_out = (float)t;
     }
+    return DR_OK;
+}
+
+int dr_solver_skip_zero_blocks(dr_context* c, int enable) {
+    CTX(c);
+    c->skip_zero = enable != 0;
     return DR_OK;
 }
 
@@ -780,6 +822,7 @@ int dr_get_info(dr_context* c, dr_info* o) {
     o->rows_per_rank = c->rpr; o->n_bvh_nodes = c->n_nodes; o->ld_F = c->ldF; o->bytes_F = c->F_floats * sizeof(float);
     o->last_assemble_ms = c->last_assemble_ms; o->last_bvh_ms = c->last_bvh_ms; o->pairs_traced = c->pairs_traced;
     o->sweep_launches = c->sweep_launches; o->sweep_ms_total = c->sweep_ms_total;
+    o->blocks_nonzero = c->mask_valid ? c->blocks_nonzero : 0; o->blocks_total = c->mask_valid ? c->blocks_total : 0;
     return DR_OK;
 }
 

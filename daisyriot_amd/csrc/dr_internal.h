@@ -97,6 +97,10 @@ struct SweepParams {
     int skew;         // per-block start-tile multiplier (0 = every block starts at column 0)
     int ksplit;       // column splits (1 = fused epilogue; >1 = partial sums + k_sweep_epilogue)
     float* Gpart;     // [ksplit][nrows][S] partial F*R sums when ksplit > 1
+    // optional: one bit per block of 32 rows x 256 columns of F, set where the block holds a non-zero; blocks whose
+    // bit is clear are not read (null = read everything).  mask_words = 32-bit words per row block.
+    const unsigned* tile_mask;
+    int mask_words;
 };
 
 // launchers implemented in the .hip files
@@ -111,6 +115,8 @@ int sweep_ksplit(int nrows, int S, int total_cols);
 hipError_t launch_patch_colors(hipStream_t st, const float* B, int nrows, int rpr, int S, int mode, const float* xyz,
                                float* rgb);
 hipError_t launch_vertex_colors(hipStream_t st, const float* rgb, int V, const int* off, const int* adj, float* out);
+// builds SweepParams::tile_mask from the resident F shard (reads it once)
+hipError_t launch_tile_mask(hipStream_t st, const float* F, int nrows, size_t ldF, unsigned* mask, int mask_words);
 hipError_t launch_colsums(hipStream_t st, const float* R, int world, int S, int rpr, double* sums);
 // layout conversion between the ABI's patch-major N x S and the device's bin-major chunks
 hipError_t launch_scatter_rows(hipStream_t st, const float* src_NxS, int N, int S, int rpr, int world,

@@ -90,19 +90,57 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
             }
     };
 
-    // Blocks start at different column tiles and wrap around: rows are a power-of-two
-    // stride apart, so lock-stepped blocks would otherwise hit the same HBM channels together.
-    int tt = (int)(((unsigned)blockIdx.x * (unsigned)P.skew) % (unsigned)ntiles);
+    // Optional list of the tiles of this block's range that hold a non-zero in its 32 rows (SweepParams::tile_mask):
+    // built in order by one wave; the loop below then runs over the list only -- no loads, no staging, no barrier
+    // for a tile that is zero in all of the block's rows.
+    constexpr int MAXT = 4096;
+    __shared__ unsigned short sTiles[MAXT];
+    __shared__ int sNT, sPos;
+    const bool use_list = (RR * NW == 32) && (P.tile_mask != nullptr) && (ntiles <= MAXT);
+    // start tile of this block (launch_sweep picks the skew); with a list: the first listed tile at or after it, so
+    // that the non-zero tiles are visited in the same order as without the list (bit-identical sums)
+    const int start_tile = (int)(((unsigned)blockIdx.x * (unsigned)P.skew) % (unsigned)ntiles);
+    int nlist = ntiles;
+    if (use_list) {
+        if (wave == 0) {
+            const unsigned* mrow = P.tile_mask + (size_t)blockIdx.x * P.mask_words;
+            int cnt = 0, below = 0;
+            for (int base = 0; base < ntiles; base += 64) {
+                const int tl = base + lane;
+                bool nzb = false;
+                if (tl < ntiles) {
+#pragma unroll
+                    for (int c = 0; c < CPL; c++) {
+                        const int bit = (tile0 + tl) * CPL + c;
+                        nzb = nzb || ((mrow[bit >> 5] >> (bit & 31)) & 1u);
+                    }
+                }
+                const unsigned long long m = __ballot(nzb);
+                if (nzb) sTiles[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)tl;
+                cnt += __popcll(m);
+                below += __popcll(__ballot(nzb && tl < start_tile));
+            }
+            if (lane == 0) { sNT = cnt; sPos = (below == cnt) ? 0 : below; }
+        }
+        __syncthreads();
+        nlist = sNT;
+    }
+    auto tile_at = [&](int pos) { return use_list ? (int)sTiles[pos] : pos; };
+
+    int pos = use_list ? sPos : start_tile;
     v4f fcur[RR][CPL], fnext[RR][CPL];
-    load_rtile(tt);
-    load_f(tt, fcur);
-    store_rtile(0);
+    if (nlist > 0) {
+        load_rtile(tile_at(pos));
+        load_f(tile_at(pos), fcur);
+        store_rtile(0);
+    }
     __syncthreads();
 
-    for (int t = 0; t < ntiles; t++) {
-        const bool more = (t + 1) < ntiles;
-        tt = (tt + 1 == ntiles) ? 0 : tt + 1;
+    for (int t = 0; t < nlist; t++) {
+        const bool more = (t + 1) < nlist;
+        pos = (pos + 1 == nlist) ? 0 : pos + 1;
         if (more) {
+            const int tt = tile_at(pos);
             load_f(tt, fnext);
             load_rtile(tt);
         }
@@ -245,20 +283,59 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_mfma(SweepParams P) {
         }
     };
 
-    int tt = (int)(((unsigned)blockIdx.x * (unsigned)P.skew) % (unsigned)ntiles);
-    load_r(tt);
-    dma_f(tt, 0);
-    store_r();
+    // optional list of the non-zero tiles (see k_sweep): a block of this kernel spans NW*16 rows = NW/2 mask rows,
+    // a tile half a mask bit
+    constexpr int MAXT = 4096;
+    __shared__ unsigned short sTiles[MAXT];
+    __shared__ int sNT, sPos;
+    const bool use_list = (NW * MT_ROWS) % 32 == 0 && (P.tile_mask != nullptr) && (ntiles <= MAXT);
+    const int start_tile = (int)(((unsigned)blockIdx.x * (unsigned)P.skew) % (unsigned)ntiles);
+    int nlist = ntiles;
+    if (use_list) {
+        if (wave == 0) {
+            constexpr int MR = NW * MT_ROWS / 32;
+            const int n_mask_rows = (P.nrows + 31) / 32;
+            int cnt = 0, below = 0;
+            for (int base = 0; base < ntiles; base += 64) {
+                const int tl = base + lane;
+                bool nzb = false;
+                if (tl < ntiles) {
+                    const int bit = ((tile0 + tl) * MT_TC) / 256;
+#pragma unroll
+                    for (int m = 0; m < MR; m++) {
+                        const int mr = blockIdx.x * MR + m;
+                        if (mr < n_mask_rows) nzb = nzb || ((P.tile_mask[(size_t)mr * P.mask_words + (bit >> 5)] >> (bit & 31)) & 1u);
+                    }
+                }
+                const unsigned long long m = __ballot(nzb);
+                if (nzb) sTiles[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)tl;
+                cnt += __popcll(m);
+                below += __popcll(__ballot(nzb && tl < start_tile));
+            }
+            if (lane == 0) { sNT = cnt; sPos = (below == cnt) ? 0 : below; }
+        }
+        __syncthreads();
+        nlist = sNT;
+    }
+    auto tile_at = [&](int pos) { return use_list ? (int)sTiles[pos] : pos; };
+
+    int pos = use_list ? sPos : start_tile;
+    if (nlist > 0) {
+        load_r(tile_at(pos));
+        dma_f(tile_at(pos), 0);
+        store_r();
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the asm DMAs are invisible to the compiler's counters
     __syncthreads();
 
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 acc0 = { 0, 0, 0, 0 }, acc1 = { 0, 0, 0, 0 };
     const int r = lane & 15, g = lane >> 4;
-    for (int t = 0; t < ntiles; t++) {
-        const bool more = (t + 1) < ntiles;
-        tt = (tt + 1 == ntiles) ? 0 : tt + 1;
+    for (int t = 0; t < nlist; t++) {
+        const bool more = (t + 1) < nlist;
+        pos = (pos + 1 == nlist) ? 0 : pos + 1;
         if (more) {
+            const int tt = tile_at(pos);
             load_r(tt);
             dma_f(tt, (t + 1) & 1);
         }
@@ -434,6 +511,44 @@ hipError_t launch_sweep(hipStream_t st, const SweepParams& p_in) {
 #undef DR_CASE
     }
     return hipErrorInvalidValue;
+}
+
+// One bit per block of 32 rows x 256 columns of the F shard: does it hold a non-zero?  A workgroup per row block,
+// a wave per 8 rows, the same 1 KiB-per-row reads as the sweep; 32 tiles are collected in a register word before
+// the one atomicOr that publishes them.  mask must be zeroed beforehand.
+__global__ __launch_bounds__(256) void k_tile_mask(const float* __restrict__ F, int nrows, size_t ldF, unsigned* __restrict__ mask,
+                                                   int mask_words) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rb = blockIdx.x;
+    const int ntiles = (int)(ldF / 256);
+    unsigned* mrow = mask + (size_t)rb * mask_words;
+    for (int w0 = blockIdx.y * 32; w0 < ntiles; w0 += gridDim.y * 32) {
+        unsigned word = 0;
+        for (int b = 0; b < 32 && w0 + b < ntiles; b++) {
+            bool nz = false;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int row = rb * 32 + wave * 8 + r;
+                if (row < nrows) {
+                    const v4f x = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(F + (size_t)row * ldF + (size_t)(w0 + b) * 256 + lane * 4));
+                    nz = nz || (x.x != 0.0f) || (x.y != 0.0f) || (x.z != 0.0f) || (x.w != 0.0f);
+                }
+            }
+            if (__ballot(nz) != 0ull) word |= 1u << b;
+        }
+        if (lane == 0 && word) atomicOr(&mrow[w0 >> 5], word);
+    }
+}
+
+hipError_t launch_tile_mask(hipStream_t st, const float* F, int nrows, size_t ldF, unsigned* mask, int mask_words) {
+    if (nrows <= 0) return hipSuccess;
+    const int row_blocks = (nrows + 31) / 32;
+    hipError_t e = hipMemsetAsync(mask, 0, sizeof(unsigned) * (size_t)row_blocks * mask_words, st);
+    if (e != hipSuccess) return e;
+    const int ntiles = (int)(ldF / 256);
+    const int gy = std::max(1, std::min((ntiles + 31) / 32, 8));
+    hipLaunchKernelGGL(k_tile_mask, dim3(row_blocks, gy), dim3(256), 0, st, F, nrows, ldF, mask, mask_words);
+    return hipGetLastError();
 }
 
 // per-bin sums of the gathered residual (check_convergence, vs/Lightning.h:255-261), double

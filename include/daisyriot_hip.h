@@ -149,6 +149,11 @@ int dr_solver_reset(dr_context* ctx);
  * B holds this rank's rows only; rows of other ranks are left untouched. */
 int dr_solver_read(dr_context* ctx, float* B, float* R);
 int dr_solver_residual_sums(dr_context* ctx, double* sums /* S */);
+/* Optional (default off): the light pass does not read blocks of 32 rows x 256 columns of F that are entirely zero
+ * (patches that cannot see each other: same wall, back to back) -- what the reference's sparse RadMat
+ * (vs/Lightning.h:19) does element-wise.  Bit-identical results (the skipped products are exact zeros); the block
+ * map is built from the resident F on the next pass (one extra read of F). */
+int dr_solver_skip_zero_blocks(dr_context* ctx, int enable);
 
 /* ---- display colours (what the viewer shows; computed from the resident B) ---- */
 #define DR_DISPLAY_BW       0   /* BWLightning::get_color_of_patch   (vs/Lightning.h:406-408): (B,B,B)        */
@@ -188,6 +193,8 @@ typedef struct {
     uint64_t pairs_traced;    /* unordered pairs traced by the last assemble */
     uint64_t sweep_launches;  /* profiled sweep launches since dr_profile_reset */
     double sweep_ms_total;    /* their summed hipEvent durations */
+    uint64_t blocks_nonzero;  /* with dr_solver_skip_zero_blocks: 32 x 256 blocks of the F shard that hold a non-zero ... */
+    uint64_t blocks_total;    /* ... of this many (0 until the first pass after enabling it) */
 } dr_info;
 int dr_get_info(dr_context* ctx, dr_info* out);
 /* record a hipEvent pair around every sweep kernel launch (on its own stream) */

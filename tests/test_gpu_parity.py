@@ -602,3 +602,47 @@ def test_multi_rank_assembly_with_ray_count_exchange(world, n, rule, uv50):
             assert np.array_equal(_bits(c.read_rows(row0, nrows)), _bits(F[row0:row0 + nrows]))
         with pytest.raises(api.DaisyRiotError):
             c.assemble_finish()                                    # nothing pending
+
+
+@pytest.mark.parametrize("S,n,world,rank", [(8, 8192, 1, 0), (3, 6000, 1, 0), (9, 8192, 1, 0), (16, 6000, 1, 0),
+                                             (8, 16384, 1, 0), (8, 8192, 2, 1), (12, 8192, 3, 2)])
+def test_zero_block_skipping_is_bit_identical(S, n, world, rank, uv50):
+    """optional dr_solver_skip_zero_blocks: passes that do not read the all-zero 32 x 256 blocks of F give the same
+    bits (the skipped products are exact zeros), on the VALU and MFMA kernels, fused and column-split, on a shard"""
+    sc = scenes.cornell_box(n, S=S, fluorescent=(S >= 8))
+    E = sc.emission(7.0)
+    with api.Context(0) as c:
+        if world > 1:
+            c.set_shard(rank, world)
+            c.comm_manual()
+        c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+        c.assemble(uv50)
+        c.solver_init(E, sc.M, sc.mat_of_patch)
+        c.step(3)
+        B0, R0 = c.read()
+        own0 = c.exchange_export() if world > 1 else None
+        assert c.info().blocks_total == 0                                  # not built unless asked for
+        c.skip_zero_blocks(True)
+        c.reset()
+        c.step(3)
+        B1, R1 = c.read()
+        i = c.info()
+        assert 0 < i.blocks_nonzero < i.blocks_total, (i.blocks_nonzero, i.blocks_total)     # something is skipped
+        row0, nrows, _ = c.shard()
+        assert np.array_equal(_bits(B1[row0:row0 + nrows]), _bits(B0[row0:row0 + nrows]))
+        if world == 1:
+            assert np.array_equal(_bits(R1), _bits(R0))
+        else:
+            assert np.array_equal(_bits(c.exchange_export()), _bits(own0))
+        # a new matrix invalidates the block map: loaded rows that fill a formerly empty block must be seen
+        rows = c.read_rows(row0, 64)
+        rows[:, :] = 1e-3
+        c.load_rows(row0, rows)
+        c.reset()
+        c.step(1)
+        Bs, _ = c.read(R=False)
+        c.skip_zero_blocks(False)
+        c.reset()
+        c.step(1)
+        Bd, _ = c.read(R=False)
+        assert np.array_equal(_bits(Bs[row0:row0 + nrows]), _bits(Bd[row0:row0 + nrows]))
