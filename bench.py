@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--bins", type=int, default=8)
     ap.add_argument("--rays", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-zero-block-report", action="store_true",
+                    help="skip the extra passes with zero-block skipping (keeps a kernel profile of this run to the dense pass)")
     ap.add_argument("--rehearse-comm", action="store_true",
                     help="single rank only: still create the torch process group and the library's RCCL communicator "
                          "(all-gather of one chunk per pass), to rehearse the multi-GPU code path on a one-GPU box")
@@ -210,28 +212,33 @@ def main():
     resid = ctx.step(0, want_sum=True)
 
     # ---- the same passes with the optional zero-block skipping (reported beside the headline, never in it) ----
-    ctx.skip_zero_blocks(True)
-    for _ in range(max(2, args.warmup)):
-        ctx.step(1)
-    ctx.synchronize()
-    ctx.profile(True)
-    ctx.profile_reset()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.step(1)
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-    dt_skip = time.perf_counter() - t0
-    ctx.profile(False)
-    info_skip = ctx.info()
-    ts = torch.tensor([dt_skip, info_skip.sweep_ms_total / max(1, info_skip.sweep_launches)], dtype=torch.float64, device="cuda")
-    if use_comm:
-        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-    dt_skip, kern_ms_skip = float(ts[0]), float(ts[1])
-    ctx.skip_zero_blocks(False)
+    skip_report = None
+    if not args.no_zero_block_report:
+        ctx.skip_zero_blocks(True)
+        for _ in range(max(2, args.warmup)):
+            ctx.step(1)
+        ctx.synchronize()
+        ctx.profile(True)
+        ctx.profile_reset()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.step(1)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        barrier()
+        dt_skip = time.perf_counter() - t0
+        ctx.profile(False)
+        info_skip = ctx.info()
+        ts = torch.tensor([dt_skip, info_skip.sweep_ms_total / max(1, info_skip.sweep_launches)], dtype=torch.float64, device="cuda")
+        if use_comm:
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        ctx.skip_zero_blocks(False)
+        skip_report = {"iters_per_s": args.steps / float(ts[0]), "kernel_ms_avg": float(ts[1]),
+                       "blocks_nonzero": int(info_skip.blocks_nonzero), "blocks_total": int(info_skip.blocks_total),
+                       "F_bytes_read_per_launch": int(info_skip.blocks_nonzero) * 32 * 256 * 4,
+                       "note": "rank 0's shard; same F, same passes, results bit-identical to the dense pass"}
 
     if rank == 0:
         n_mat = sc.M.shape[0]
@@ -261,10 +268,7 @@ def main():
             "residual_sum_after_timed_passes": resid,
             # optional dr_solver_skip_zero_blocks: all-zero 32 x 256 blocks of F are not read (bit-identical results);
             # not part of "value" -- the headline streams the whole dense matrix
-            "zero_block_skipping": {"iters_per_s": args.steps / dt_skip, "kernel_ms_avg": kern_ms_skip,
-                                    "blocks_nonzero": int(info_skip.blocks_nonzero), "blocks_total": int(info_skip.blocks_total),
-                                    "F_bytes_read_per_launch": int(info_skip.blocks_nonzero) * 32 * 256 * 4,
-                                    "note": "rank 0's shard; same F, same passes, results bit-identical to the dense pass"},
+            "zero_block_skipping": skip_report,
         }
         if world == 1 and not args.no_cpu_baseline:
             sweep_cpu, ff_cpu, allcores = cpu_baselines(ctx, sc, uv, 65536, 2)
