@@ -24,10 +24,8 @@ SpectralUpsampler::SpectralUpsampler(const std::string& path) {
         scale_.resize(res);
         data_.resize((size_t)res * res * res * 9);
         if (std::fread(scale_.data(), sizeof(float), res, f) == res &&
-            std::fread(data_.data(), sizeof(float), data_.size(), f) == data_.size()) {
+            std::fread(data_.data(), sizeof(float), data_.size(), f) == data_.size())
             res_ = res;
-            std::printf("Loading \"%s\" .. \n", path.c_str());          // rgb2spec.cpp:22
-        }
     }
     std::fclose(f);
     if (!res_) { scale_.clear(); data_.clear(); }
@@ -250,6 +248,7 @@ void MeshS::loadFromFile(const char* filepath, const char* mtldir, const std::ve
 
     // materials, classified as MeshS.cpp:36-66 does
     SpectralUpsampler up;
+    if (up.has_table()) std::printf("Loading \"color_tables/srgb.coeff\" .. \n");          // rgb2spec.cpp:22
     for (const MtlEntry& e : mtl) {
         const bool blacklightsource = (e.Ke.x + e.Ke.y + e.Ke.z > 0) && (e.Kd.x + e.Kd.y + e.Kd.z == 0.0f);
         const bool fluorescent = (e.Ks.x + e.Ks.y + e.Ks.z > 0.0f);

@@ -238,6 +238,18 @@ def ref():
         R.ref_light_pass.argtypes = [C.c_int, C.c_int, fp, fp, ip, fp, fp, C.c_int]
         R.ref_sum.restype = C.c_float
         R.ref_sum.argtypes = [C.c_int, fp]
+        R.ref_ini_open.restype = C.c_void_p
+        R.ref_ini_open.argtypes = [C.c_char_p]
+        R.ref_ini_free.argtypes = [C.c_void_p]
+        R.ref_ini_error.argtypes = [C.c_void_p]
+        R.ref_ini_get.restype = C.c_char_p
+        R.ref_ini_get.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
+        R.ref_ini_integer.restype = C.c_long
+        R.ref_ini_integer.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_long]
+        R.ref_ini_real.restype = C.c_double
+        R.ref_ini_real.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_double]
+        R.ref_ini_boolean.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
+        R.ref_rgb2spec_spectrum.argtypes = [C.c_char_p, fp, fp, C.c_int, fp]
         R.ref_xyz_fit.argtypes = [C.c_double, fp]
         R.ref_patch_color_spectral.argtypes = [C.c_int, fp, fp, fp]
         R.ref_vertex_color.argtypes = [C.c_int, ip, fp, fp]
@@ -306,3 +318,32 @@ def ref_vertex_colors(vtx_off, vtx_tri, rgb):
         ref().ref_vertex_color(n, _p(a), _p(rgb), _p(o))
         out[v] = o
     return out
+
+
+def ref_ini_query(path, queries):
+    """the reference's own INIReader on the file at `path`: queries = [(kind, section, name, default)], kind in
+    get / integer / real / boolean; returns (ParseError(), [values])"""
+    R = ref()
+    h = R.ref_ini_open(path.encode())
+    out = []
+    for kind, sec, name, default in queries:
+        sec, name = sec.encode(), name.encode()
+        if kind == "get":
+            out.append(R.ref_ini_get(h, sec, name, default.encode()).decode())
+        elif kind == "integer":
+            out.append(int(R.ref_ini_integer(h, sec, name, int(default))))
+        elif kind == "real":
+            out.append(float(R.ref_ini_real(h, sec, name, float(default))))
+        else:
+            out.append(int(R.ref_ini_boolean(h, sec, name, int(default))))
+    err = int(R.ref_ini_error(h))
+    R.ref_ini_free(h)
+    return err, out
+
+
+def ref_rgb2spec_spectrum(path, rgb, wavelengths):
+    """Material::rgb_to_spectrum through the reference's own rgb2spec.cpp on the coefficient table at `path`"""
+    rgb, wl = _f32(rgb), _f32(wavelengths)
+    out = np.zeros(wl.size, np.float32)
+    ok = ref().ref_rgb2spec_spectrum(path.encode(), _p(rgb), _p(wl), wl.size, _p(out))
+    return int(ok), out

@@ -10,6 +10,9 @@
  *     cwiseProduct and MatrixXf * VectorXf exactly as vs/Lightning.h:196-226 and
  *     :342-349 write them -> sparse product must equal oracle.c bit for bit.
  *
+ *   - config.ini parsing and the RGB -> spectrum table lookup go through the reference's own
+ *     "visual studio/INIReader.h" (single header) and "visual studio/rgb2spec.cpp" (needs nothing but libc),
+ *     compiled as they lie;
  *   - the display colour is evaluated through the reference's own
  *     "visual studio/color.h" (a first-party header that needs nothing but glm),
  *     included from where it lies, at the call site of vs/Lightning.h:168-183.
@@ -29,6 +32,9 @@
 #include <Eigen/Sparse>
 
 #include "color.h"      /* $(REF)/visual studio/color.h */
+#include "INIReader.h"  /* $(REF)/visual studio/INIReader.h: the reference's single-header ini parser, as it lies */
+#include "rgb2spec.h"   /* $(REF)/visual studio/rgb2spec.h; rgb2spec.cpp is compiled beside this file (oracle/Makefile) */
+#include <string>
 
 namespace {
 
@@ -177,6 +183,32 @@ void ref_patch_color_spectral(int S, const float* xyz_per_bin, const float* b, f
     float maxval = std::fmax(rgb[0], std::fmax(rgb[1], rgb[2]));
     if (maxval > 1) rgb = { rgb[0] / maxval, rgb[1] / maxval, rgb[2] / maxval };
     rgb3[0] = rgb[0]; rgb3[1] = rgb[1]; rgb3[2] = rgb[2];
+}
+
+/* the reference's own INIReader (main.cpp:63-79 reads config.ini through it) */
+void* ref_ini_open(const char* path) { return new INIReader(path); }
+void ref_ini_free(void* h) { delete (INIReader*)h; }
+int ref_ini_error(void* h) { return ((INIReader*)h)->ParseError(); }
+const char* ref_ini_get(void* h, const char* sec, const char* name, const char* def) {
+    static std::string tmp;
+    tmp = ((INIReader*)h)->Get(sec, name, def);
+    return tmp.c_str();
+}
+long ref_ini_integer(void* h, const char* sec, const char* name, long def) { return ((INIReader*)h)->GetInteger(sec, name, def); }
+double ref_ini_real(void* h, const char* sec, const char* name, double def) { return ((INIReader*)h)->GetReal(sec, name, def); }
+int ref_ini_boolean(void* h, const char* sec, const char* name, int def) { return ((INIReader*)h)->GetBoolean(sec, name, def != 0) ? 1 : 0; }
+
+/* Material::rgb_to_spectrum (vs/Material.cpp:35-45) through the reference's own rgb2spec_load / rgb2spec_fetch /
+ * rgb2spec_eval_precise (vs/rgb2spec.cpp:11-134) on the table at `path`; returns 0 if the table does not load */
+int ref_rgb2spec_spectrum(const char* path, const float* rgb_in, const float* wavelengths, int S, float* out) {
+    RGB2Spec* model = rgb2spec_load(path);
+    if (!model) return 0;
+    float coeff[3];
+    float rgb[3] = { rgb_in[0], rgb_in[1], rgb_in[2] };
+    rgb2spec_fetch(model, rgb, coeff);
+    for (int i = 0; i < S; i++) out[i] = rgb2spec_eval_precise(coeff, wavelengths[i]);
+    rgb2spec_free(model);
+    return 1;
 }
 
 /* one corner of Drawer::interpolate (vs/Drawer.cpp:161-186): sum of the adjacent patches' colours / count */

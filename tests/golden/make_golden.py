@@ -85,12 +85,91 @@ def display():
     print("wrote display_color_h.npz: %d patches, %d above 1 before normalisation" % (B.shape[0], int((rgb.max(axis=1) >= 1).sum())))
 
 
+INI_TEXT = b"""; a config in the shape of the reference's config_example.ini, plus the parser's corner cases
+
+[window]             ; Window configuration
+width = 800
+height = 600
+
+[filepaths]\t\t\t; Necesarry directories
+scene = example_scenes/cornellbox_blacklight.obj
+mtl_dir = example_scenes/
+
+[drawing]
+radiosityRendering = true
+antiAliasing = TRUE
+supersampling = 4
+
+[lightning]\t\t\t; Lightning configuration
+emission_value = 7.0 ; Best to adjust this value per scene
+method = 2\t\t\t; 0 = BW, 1 = RGB, 2 = Spectral
+method = 1
+[acceleration]
+cuda_on = yes
+hexval : 0x10
+negative = -12
+float_as_int = 3.9
+spaced key   =   spaced value   
+# hash comment
+off_switch = off
+  indented = 5
+empty =
+"""
+
+INI_QUERIES = [("integer", "window", "width", -1), ("integer", "window", "height", -1), ("integer", "window", "depth", -7),
+               ("get", "filepaths", "scene", "UNKNOWN"), ("get", "filepaths", "mtl_dir", "UNKNOWN"), ("get", "filepaths", "nope", "UNKNOWN"),
+               ("boolean", "drawing", "radiosityRendering", 0), ("boolean", "drawing", "antiAliasing", 0),
+               ("boolean", "drawing", "supersampling", 1), ("integer", "drawing", "supersampling", 0),
+               ("real", "lightning", "emission_value", -1.0), ("integer", "lightning", "method", 0), ("integer", "LIGHTNING", "Method", 0),
+               ("get", "lightning", "method", ""), ("boolean", "acceleration", "cuda_on", 0), ("integer", "acceleration", "hexval", 0),
+               ("integer", "acceleration", "negative", 0), ("integer", "acceleration", "float_as_int", 0), ("real", "acceleration", "float_as_int", 0.0),
+               ("get", "acceleration", "spaced key", "?"), ("boolean", "acceleration", "off_switch", 1), ("integer", "acceleration", "indented", 0),
+               ("get", "acceleration", "empty", "default"), ("real", "window", "width", 0.5)]
+
+
+def host_surface():
+    """config.ini parsing and RGB -> spectrum table lookup through the reference's own INIReader.h and rgb2spec.cpp
+    (oracle/_ref), on a config of this file's own and on a small coefficient table made by lib/rgb2spec_opt"""
+    import json
+    import subprocess
+    import tempfile
+    assert ob.ref_available()
+    with tempfile.TemporaryDirectory() as d:
+        ini = os.path.join(d, "config.ini")
+        open(ini, "wb").write(INI_TEXT)
+        err, vals = ob.ref_ini_query(ini, INI_QUERIES)
+        bad = os.path.join(d, "bad.ini")
+        open(bad, "wb").write(b"[a]\nok = 1\nthis line has no separator\nx = 2\n")
+        err_bad, vals_bad = ob.ref_ini_query(bad, [("integer", "a", "x", 0), ("integer", "a", "ok", 0)])
+        err_missing, _ = ob.ref_ini_query(os.path.join(d, "missing.ini"), [])
+        json.dump({"ini_text": INI_TEXT.decode(), "queries": INI_QUERIES, "parse_error": err, "values": vals,
+                   "bad_text": "[a]\nok = 1\nthis line has no separator\nx = 2\n", "bad_parse_error": err_bad, "bad_values": vals_bad,
+                   "missing_parse_error": err_missing}, open(os.path.join(OUT, "ini_inireader.json"), "w"), indent=1)
+        table = os.path.join(d, "srgb8.coeff")
+        subprocess.run([os.path.join(ROOT, "daisyriot_amd", "lib", "rgb2spec_opt"), "8", table], check=True, capture_output=True)
+        rs = np.random.RandomState(11)
+        rgb = rs.uniform(0, 1, size=(60, 3)).astype(np.float32)
+        rgb[:6] = [[1, 1, 1], [0.5, 0.5, 0.5], [1, 0, 0], [0, 1, 0], [0, 0, 1], [0.63, 0.065, 0.05]]
+        wl = np.concatenate([np.arange(200.0, 601.0, 50.0), np.arange(380.0, 781.0, 25.0)]).astype(np.float32)
+        spectra = np.zeros((60, wl.size), np.float32)
+        for k in range(60):
+            ok, spectra[k] = ob.ref_rgb2spec_spectrum(table, rgb[k], wl)
+            assert ok == 1
+        np.savez_compressed(os.path.join(OUT, "rgb2spec_lookup.npz"), table=np.frombuffer(open(table, "rb").read(), np.uint8),
+                            rgb=rgb, wavelengths=wl, spectra_bits=spectra.view(np.uint32))
+    print("wrote ini_inireader.json (parse error %d) and rgb2spec_lookup.npz" % err)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "host":
+        host_surface()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "display":
         display()
         sys.exit(0)
     main()
     display()
+    host_surface()
 
 
 def reference_scenes():

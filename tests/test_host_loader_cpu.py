@@ -186,3 +186,64 @@ def test_xyz_fit_table_equals_the_reference_header(host):
         host.drh_xyz_fit(float(w), o.ctypes.data_as(C.c_void_p))
         got[k] = o
     assert np.array_equal(got.view(np.uint32), g["xyz_bits"])
+
+
+def _host_ini_query(host, path, queries):
+    h = host.drh_ini_open(path.encode())
+    out = []
+    for kind, sec, name, default in queries:
+        sec, name = sec.encode(), name.encode()
+        if kind == "get":
+            out.append(host.drh_ini_get(h, sec, name, default.encode()).decode())
+        elif kind == "integer":
+            out.append(int(host.drh_ini_integer(h, sec, name, int(default))))
+        elif kind == "real":
+            out.append(float(host.drh_ini_real(h, sec, name, float(default))))
+        else:
+            out.append(int(host.drh_ini_boolean(h, sec, name, int(default))))
+    err = int(host.drh_ini_error(h))
+    host.drh_ini_free(h)
+    return err, out
+
+
+def test_ini_reader_equals_the_reference_inireader(host, tmp_path):
+    """golden values produced by the reference's own INIReader.h (tests/golden/make_golden.py host): duplicate keys,
+    continuation lines, inline comments, ':' separators, hex and negative integers, boolean spellings, defaults"""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ini_inireader.json")))
+    p = tmp_path / "config.ini"
+    p.write_bytes(g["ini_text"].encode())
+    queries = [tuple(q) for q in g["queries"]]
+    err, vals = _host_ini_query(host, str(p), queries)
+    assert err == g["parse_error"]
+    for q, got, want in zip(queries, vals, g["values"]):
+        assert got == want, (q, got, want)
+    b = tmp_path / "bad.ini"
+    b.write_bytes(g["bad_text"].encode())
+    err, vals = _host_ini_query(host, str(b), [("integer", "a", "x", 0), ("integer", "a", "ok", 0)])
+    assert err == g["bad_parse_error"] and vals == g["bad_values"]
+    err, _ = _host_ini_query(host, str(tmp_path / "missing.ini"), [])
+    assert err == g["missing_parse_error"]
+    from oracle import binding as ob
+    if ob.ref_available():                                  # and live, when the checker library is there
+        assert ob.ref_ini_query(str(p), queries) == (g["parse_error"], g["values"])
+
+
+def test_spectrum_lookup_equals_the_reference_rgb2spec(host, tmp_path):
+    """rgb2spec_fetch + rgb2spec_eval_precise of the reference (vs/rgb2spec.cpp:78-134, as Material.cpp:35-45 calls
+    them) on a small coefficient table: the host's SpectralUpsampler gives the same bits"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rgb2spec_lookup.npz"))
+    table = tmp_path / "srgb8.coeff"
+    table.write_bytes(g["table"].tobytes())
+    host.drh_upsample.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    wl = np.ascontiguousarray(g["wavelengths"], np.float32)
+    want = g["spectra_bits"]
+    for k, rgb in enumerate(np.ascontiguousarray(g["rgb"], np.float32)):
+        out = np.zeros(wl.size, np.float32)
+        assert host.drh_upsample(str(table).encode(), rgb.ctypes.data_as(C.c_void_p), wl.ctypes.data_as(C.c_void_p), wl.size,
+                                 out.ctypes.data_as(C.c_void_p)) == 1
+        assert np.array_equal(out.view(np.uint32), want[k]), (k, rgb)
+    from oracle import binding as ob
+    if ob.ref_available():
+        ok, sp = ob.ref_rgb2spec_spectrum(str(table), g["rgb"][7], wl)
+        assert ok == 1 and np.array_equal(sp.view(np.uint32), want[7])
