@@ -250,6 +250,13 @@ def ref():
         R.ref_ini_real.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_double]
         R.ref_ini_boolean.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
         R.ref_rgb2spec_spectrum.argtypes = [C.c_char_p, fp, fp, C.c_int, fp]
+        R.ref_obj_load.restype = C.c_void_p
+        R.ref_obj_load.argtypes = [C.c_char_p, C.c_char_p]
+        R.ref_obj_free.argtypes = [C.c_void_p]
+        R.ref_obj_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 5
+        R.ref_obj_copy.argtypes = [C.c_void_p] + [fp] * 8
+        R.ref_obj_material_name.restype = C.c_char_p
+        R.ref_obj_material_name.argtypes = [C.c_void_p, C.c_int]
         R.ref_xyz_fit.argtypes = [C.c_double, fp]
         R.ref_patch_color_spectral.argtypes = [C.c_int, fp, fp, fp]
         R.ref_vertex_color.argtypes = [C.c_int, ip, fp, fp]
@@ -347,3 +354,19 @@ def ref_rgb2spec_spectrum(path, rgb, wavelengths):
     out = np.zeros(wl.size, np.float32)
     ok = ref().ref_rgb2spec_spectrum(path.encode(), _p(rgb), _p(wl), wl.size, _p(out))
     return int(ok), out
+
+
+def ref_obj_load(obj, mtl_dir):
+    """the vendored tinyobjloader as MeshS::loadFromFile calls it; dict of the arrays MeshS takes from it"""
+    R = ref()
+    h = R.ref_obj_load(obj.encode(), mtl_dir.encode())
+    ok, V, Nn, N, nm = (C.c_int() for _ in range(5))
+    R.ref_obj_counts(h, C.byref(ok), C.byref(V), C.byref(Nn), C.byref(N), C.byref(nm))
+    out = dict(vertices=np.zeros((V.value, 3), np.float32), normals=np.zeros((Nn.value, 3), np.float32),
+               tri_v=np.zeros((N.value, 3), np.int32), tri_n=np.zeros((N.value, 3), np.int32), mat=np.zeros(N.value, np.int32),
+               Kd=np.zeros((nm.value, 3), np.float32), Ke=np.zeros((nm.value, 3), np.float32), Ks=np.zeros((nm.value, 3), np.float32))
+    R.ref_obj_copy(h, *[_p(out[k]) for k in ("vertices", "normals", "tri_v", "tri_n", "mat", "Kd", "Ke", "Ks")])
+    out["names"] = [R.ref_obj_material_name(h, m).decode() for m in range(nm.value)]
+    out["ok"] = ok.value
+    R.ref_obj_free(h)
+    return out

@@ -10,6 +10,7 @@
  *     cwiseProduct and MatrixXf * VectorXf exactly as vs/Lightning.h:196-226 and
  *     :342-349 write them -> sparse product must equal oracle.c bit for bit.
  *
+ *   - OBJ/MTL parsing goes through the vendored tinyobjloader exactly as vs/MeshS.cpp:25-31 calls it;
  *   - config.ini parsing and the RGB -> spectrum table lookup go through the reference's own
  *     "visual studio/INIReader.h" (single header) and "visual studio/rgb2spec.cpp" (needs nothing but libc),
  *     compiled as they lie;
@@ -35,6 +36,8 @@
 #include "INIReader.h"  /* $(REF)/visual studio/INIReader.h: the reference's single-header ini parser, as it lies */
 #include "rgb2spec.h"   /* $(REF)/visual studio/rgb2spec.h; rgb2spec.cpp is compiled beside this file (oracle/Makefile) */
 #include <string>
+#define TINYOBJLOADER_IMPLEMENTATION
+#include <tinyobjloader/tiny_obj_loader.h>   /* $(REF)/libraries/tinyobjloader: the vendored OBJ/MTL parser MeshS.cpp calls */
 
 namespace {
 
@@ -210,6 +213,50 @@ int ref_rgb2spec_spectrum(const char* path, const float* rgb_in, const float* wa
     rgb2spec_free(model);
     return 1;
 }
+
+/* tinyobj::LoadObj exactly as MeshS::loadFromFile calls it (vs/MeshS.cpp:25-31: triangulate = false), flattened the
+ * way its loops read the result (vs/MeshS.cpp:67-126): corners in shape order, three per triangle */
+struct RefObj {
+    tinyobj::attrib_t attrib;
+    std::vector<tinyobj::shape_t> shapes;
+    std::vector<tinyobj::material_t> materials;
+    std::string err;
+    bool ok;
+    std::vector<int> tri_v, tri_n, mat;
+};
+void* ref_obj_load(const char* obj, const char* mtl_dir) {
+    RefObj* r = new RefObj();
+    r->ok = tinyobj::LoadObj(&r->attrib, &r->shapes, &r->materials, &r->err, obj, mtl_dir, false);
+    for (size_t i = 0; i < r->shapes.size(); i++) {
+        tinyobj::shape_t& shape = r->shapes[i];
+        for (size_t j = 0; j + 2 < shape.mesh.indices.size(); j += 3) {
+            for (int k = 0; k < 3; k++) {
+                r->tri_v.push_back(shape.mesh.indices[j + k].vertex_index);
+                r->tri_n.push_back(shape.mesh.indices[j + k].normal_index);
+            }
+            r->mat.push_back(shape.mesh.material_ids[j / 3]);
+        }
+    }
+    return r;
+}
+void ref_obj_free(void* h) { delete (RefObj*)h; }
+void ref_obj_counts(void* h, int* ok, int* V, int* Nn, int* N, int* n_mat) {
+    RefObj* r = (RefObj*)h;
+    *ok = r->ok ? 1 : 0; *V = (int)(r->attrib.vertices.size() / 3); *Nn = (int)(r->attrib.normals.size() / 3);
+    *N = (int)r->mat.size(); *n_mat = (int)r->materials.size();
+}
+void ref_obj_copy(void* h, float* vertices, float* normals, int* tri_v, int* tri_n, int* mat, float* Kd, float* Ke, float* Ks) {
+    RefObj* r = (RefObj*)h;
+    for (size_t i = 0; i < r->attrib.vertices.size(); i++) vertices[i] = r->attrib.vertices[i];
+    for (size_t i = 0; i < r->attrib.normals.size(); i++) normals[i] = r->attrib.normals[i];
+    for (size_t i = 0; i < r->tri_v.size(); i++) { tri_v[i] = r->tri_v[i]; tri_n[i] = r->tri_n[i]; }
+    for (size_t i = 0; i < r->mat.size(); i++) mat[i] = r->mat[i];
+    for (size_t m = 0; m < r->materials.size(); m++)
+        for (int k = 0; k < 3; k++) {
+            Kd[3 * m + k] = r->materials[m].diffuse[k]; Ke[3 * m + k] = r->materials[m].emission[k]; Ks[3 * m + k] = r->materials[m].specular[k];
+        }
+}
+const char* ref_obj_material_name(void* h, int m) { return ((RefObj*)h)->materials[(size_t)m].name.c_str(); }
 
 /* one corner of Drawer::interpolate (vs/Drawer.cpp:161-186): sum of the adjacent patches' colours / count */
 void ref_vertex_color(int n_adj, const int32_t* adj, const float* rgb_patches, float* out3) {

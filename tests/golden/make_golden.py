@@ -160,7 +160,99 @@ def host_surface():
     print("wrote ini_inireader.json (parse error %d) and rgb2spec_lookup.npz" % err)
 
 
+OBJ_TEXT = b"""# corner cases of the OBJ dialect the reference's scenes use (Blender export) and a few more
+mtllib case.mtl
+o Cube
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 0 0 1
+v 1 0 1
+v 1 1 1
+v 0 1 1
+vn 0 0 -1
+vn 0 0 1
+vn 1 0 0
+vt 0.5 0.5
+usemtl wall
+s off
+f 1//1 3//1 2//1
+f 1//1 4//1 3//1
+g top   
+usemtl lamp
+f 5/1/2 6/1/2 7/1/2
+f 5/1/2 7/1/2 8/1/2
+
+# relative indices, a trailing comment and tabs
+usemtl wall
+f -8//-3 -7//-3\t-3//-1
+o Second\r
+v 2 0 0
+v 3 0 0
+v 2 1 0
+vn 0 1 0
+usemtl uv
+f 9//4 10//4 11//4\r
+usemtl glow
+f 11//4 10//4 9//4
+"""
+
+MTL_TEXT = b"""# materials in the reference's conventions (MeshS.cpp:41-63): Ks marks fluorescent, the name Blacklight the UV lamp
+newmtl wall
+Ns 96.078431
+Ka 1.000000 1.000000 1.000000
+Kd 0.640000 0.050000 0.050000
+Ks 0.000000 0.000000 0.000000
+Ke 0.0 0.0 0.0
+Ni 1.000000
+d 1.000000
+illum 2
+
+newmtl lamp
+Kd 0.78 0.78 0.78
+Ke 1.0 0.9 0.8
+Ks 0 0 0
+
+newmtl uv
+Kd 0.1 0.1 0.1
+Ke 0 0 0
+Ks 0.2 0.3 0.9
+map_Kd unused.png
+
+newmtl glow
+Kd 0.5 0.5 0.5
+Ks 0 0 0
+"""
+
+
+def obj_loader():
+    """OBJ/MTL through the vendored tinyobjloader as MeshS::loadFromFile calls it (oracle/_ref): expected arrays for a
+    synthetic file with the dialect's corner cases, plus the reference's two example scenes as a check on the run"""
+    import tempfile
+    assert ob.ref_available()
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "case.obj"), "wb").write(OBJ_TEXT)
+        open(os.path.join(d, "case.mtl"), "wb").write(MTL_TEXT)
+        r = ob.ref_obj_load(os.path.join(d, "case.obj"), d + "/")
+    assert r["ok"] == 1
+    np.savez_compressed(os.path.join(OUT, "obj_tinyobj.npz"), obj_text=np.frombuffer(OBJ_TEXT, np.uint8), mtl_text=np.frombuffer(MTL_TEXT, np.uint8),
+                        vertices=r["vertices"], normals=r["normals"], tri_v=r["tri_v"], tri_n=r["tri_n"], mat=r["mat"],
+                        Kd=r["Kd"], Ke=r["Ke"], Ks=r["Ks"], names=np.array(r["names"]))
+    print("wrote obj_tinyobj.npz:", r["tri_v"].shape[0], "triangles,", r["names"])
+    ex = "/root/reference/example_scenes"
+    for name in ("cornellbox_blacklight", "colorballs"):
+        t = ob.ref_obj_load("%s/%s.obj" % (ex, name), ex + "/")
+        g = np.load(os.path.join(OUT, "scene_%s.npz" % name))
+        for k in ("vertices", "normals", "tri_v", "tri_n", "mat", "Kd"):
+            assert np.array_equal(t[k], g[k]), (name, k)        # the committed scene fixtures (made by the host loader) agree
+    print("example scenes: host-loader fixtures equal tinyobj's arrays")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "obj":
+        obj_loader()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "host":
         host_surface()
         sys.exit(0)
@@ -170,6 +262,7 @@ if __name__ == "__main__":
     main()
     display()
     host_surface()
+    obj_loader()
 
 
 def reference_scenes():

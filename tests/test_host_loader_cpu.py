@@ -247,3 +247,31 @@ def test_spectrum_lookup_equals_the_reference_rgb2spec(host, tmp_path):
     if ob.ref_available():
         ok, sp = ob.ref_rgb2spec_spectrum(str(table), g["rgb"][7], wl)
         assert ok == 1 and np.array_equal(sp.view(np.uint32), want[7])
+
+
+def test_obj_mtl_parsing_equals_the_vendored_tinyobjloader(host, tmp_path):
+    """expected arrays produced by the reference's vendored tinyobjloader, called as vs/MeshS.cpp:25-31 calls it
+    (tests/golden/make_golden.py obj): v//vn and v/vt/vn corners, relative indices, groups, CR line ends, tabs,
+    several usemtl switches, unknown .mtl keys"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "obj_tinyobj.npz"))
+    (tmp_path / "case.obj").write_bytes(g["obj_text"].tobytes())
+    (tmp_path / "case.mtl").write_bytes(g["mtl_text"].tobytes())
+    got = load(host, str(tmp_path / "case.obj"), str(tmp_path) + "/")
+    for k in ("vertices", "normals", "tri_v", "tri_n", "mat"):
+        assert np.array_equal(got[k], g[k]), k
+    assert np.array_equal(got["rgb"], g["Kd"])                         # Material::rgbcolor = Kd (MeshS.cpp:37)
+    # classification (MeshS.cpp:41-63): Ks > 0 -> fluorescent; emission of plain materials = Ke
+    assert got["kind"].tolist() == [0, 0, 2, 0]
+    assert np.array_equal(got["emission"][[0, 1, 3]], g["Ke"][[0, 1, 3]])
+    from oracle import binding as ob
+    if ob.ref_available():
+        live = ob.ref_obj_load(str(tmp_path / "case.obj"), str(tmp_path) + "/")
+        for k in ("vertices", "normals", "tri_v", "tri_n", "mat", "Kd", "Ke", "Ks"):
+            assert np.array_equal(live[k], g[k]), k
+        if os.path.isdir(REF_SCENES):
+            for name in ("cornellbox_blacklight", "colorballs"):
+                t = ob.ref_obj_load("%s/%s.obj" % (REF_SCENES, name), REF_SCENES + "/")
+                mine = load(host, "%s/%s.obj" % (REF_SCENES, name), REF_SCENES + "/")
+                for k in ("vertices", "normals", "tri_v", "tri_n", "mat"):
+                    assert np.array_equal(t[k], mine[k]), (name, k)
+                assert np.array_equal(t["Kd"], mine["rgb"])
