@@ -71,6 +71,18 @@ int drh_upsample(const char* coeff_path, const float* rgb, const float* waveleng
     return up.has_table() ? 1 : 0;
 }
 
+int drh_fcache_write(const char* path, int N, const float* dense) {
+    std::vector<float> d(dense, dense + (size_t)N * N);
+    write_fcache(path, N, d);
+    return 1;
+}
+int drh_fcache_read(const char* path, int N, float* dense) {
+    std::vector<float> d;
+    if (!read_fcache(path, N, d)) return 0;
+    for (size_t k = 0; k < d.size(); k++) dense[k] = d[k];
+    return 1;
+}
+
 void drh_xyz_fit(double wavelength, float* out3) { vec3 v = cie1931_xyz_fit(wavelength); out3[0] = v.x; out3[1] = v.y; out3[2] = v.z; }
 
 void drh_visibility_samples(int K, unsigned seed, float* uv) {

@@ -30,12 +30,6 @@ vec3 cie1931_xyz_fit(double w) {
     return vec3{ (float)x, (float)y, (float)z };
 }
 
-namespace {
-
-void chk(int rc, const char* what) {
-    if (rc != DR_OK) throw HipError(std::string(what) + ": " + dr_last_error());
-}
-
 // Reader/writer of the reference's F cache (Lightning.h:21-74): ints rows, cols, nnz, outerSize, innerSize,
 // then float values[nnz], int outerIndex[outerSize] (not outerSize+1), int innerIndex[nnz] of the
 // column-major compressed matrix RadMat(i,j) = F(i->j).
@@ -78,6 +72,12 @@ void write_fcache(const char* path, int N, const std::vector<float>& dense) {
     f.write((const char*)val.data(), sizeof(float) * val.size());
     f.write((const char*)outer.data(), sizeof(int) * outer.size());
     f.write((const char*)inner.data(), sizeof(int) * inner.size());
+}
+
+namespace {
+
+void chk(int rc, const char* what) {
+    if (rc != DR_OK) throw HipError(std::string(what) + ": " + dr_last_error());
 }
 
 class LightningHIP : public Lightning {

@@ -21,6 +21,10 @@ std::vector<UV> make_visibility_samples(int K = DR_RAYS_PER_PATCH, unsigned seed
 // xyz_per_wavelength entry of SpectralLightning (color.h:14-45)
 vec3 cie1931_xyz_fit(double wavelength);
 
+// F-matrix disk cache in the reference's format (Lightning.h:21-74): dense N x N row-major <-> file
+bool read_fcache(const char* path, int N, std::vector<float>& dense);
+void write_fcache(const char* path, int N, const std::vector<float>& dense);
+
 struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
 
 class Lightning {

@@ -250,6 +250,8 @@ def ref():
         R.ref_ini_real.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_double]
         R.ref_ini_boolean.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
         R.ref_rgb2spec_spectrum.argtypes = [C.c_char_p, fp, fp, C.c_int, fp]
+        R.ref_fcache_write.argtypes = [C.c_char_p, C.c_int, fp]
+        R.ref_fcache_read.argtypes = [C.c_char_p, C.c_int, fp]
         R.ref_obj_load.restype = C.c_void_p
         R.ref_obj_load.argtypes = [C.c_char_p, C.c_char_p]
         R.ref_obj_free.argtypes = [C.c_void_p]
@@ -370,3 +372,15 @@ def ref_obj_load(obj, mtl_dir):
     out["ok"] = ok.value
     R.ref_obj_free(h)
     return out
+
+
+def ref_fcache_write(path, dense):
+    """SerializeMat (vs/Lightning.h:21-45) of the dense N x N matrix through the reference's Eigen"""
+    dense = _f32(dense)
+    return int(ref().ref_fcache_write(path.encode(), dense.shape[0], _p(dense)))
+
+
+def ref_fcache_read(path, N):
+    """DeserializeMat (vs/Lightning.h:46-74) through the reference's Eigen; dense N x N or None"""
+    out = np.zeros((N, N), np.float32)
+    return out if ref().ref_fcache_read(path.encode(), int(N), _p(out)) else None

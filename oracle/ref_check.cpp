@@ -25,6 +25,7 @@
  * TEST INFRASTRUCTURE ONLY.
  */
 #include <cmath>
+#include <cstdio>
 #include <cstdint>
 #include <vector>
 
@@ -211,6 +212,53 @@ int ref_rgb2spec_spectrum(const char* path, const float* rgb_in, const float* wa
     rgb2spec_fetch(model, rgb, coeff);
     for (int i = 0; i < S; i++) out[i] = rgb2spec_eval_precise(coeff, wavelengths[i]);
     rgb2spec_free(model);
+    return 1;
+}
+
+/* The F-matrix disk cache (vs/Lightning.h:21-74), restated call for call on the reference's Eigen: SerializeMat dumps
+ * rows, cols, nonZeros, outerSize, innerSize, then valuePtr (nnz floats), outerIndexPtr (outerSize ints -- not
+ * outerSize + 1) and innerIndexPtr (nnz ints) of the compressed column-major matrix; DeserializeMat reads them back.
+ * dense: N x N row-major, dense[i*N + j] = RadMat(i, j). */
+int ref_fcache_write(const char* path, int N, const float* dense) {
+    typedef Eigen::SparseMatrix<float> SpMat;
+    std::vector<Eigen::Triplet<float>> trip;
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++)
+            if (dense[(long)i * N + j] != 0.0f) trip.push_back(Eigen::Triplet<float>(i, j, dense[(long)i * N + j]));
+    SpMat m(N, N);
+    m.setFromTriplets(trip.begin(), trip.end());
+    m.makeCompressed();
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return 0;
+    int rows = m.rows(), cols = m.cols(), nnzs = m.nonZeros(), outS = m.outerSize(), innS = m.innerSize();
+    std::fwrite(&rows, sizeof(int), 1, f); std::fwrite(&cols, sizeof(int), 1, f); std::fwrite(&nnzs, sizeof(int), 1, f);
+    std::fwrite(&outS, sizeof(int), 1, f); std::fwrite(&innS, sizeof(int), 1, f);
+    std::fwrite(m.valuePtr(), sizeof(float), m.nonZeros(), f);
+    std::fwrite(m.outerIndexPtr(), sizeof(int), m.outerSize(), f);
+    std::fwrite(m.innerIndexPtr(), sizeof(int), m.nonZeros(), f);
+    std::fclose(f);
+    return 1;
+}
+int ref_fcache_read(const char* path, int N, float* dense) {
+    typedef Eigen::SparseMatrix<float> SpMat;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return 0;
+    int rows, cols, nnz, inSz, outSz;
+    bool ok = std::fread(&rows, sizeof(int), 1, f) == 1 && std::fread(&cols, sizeof(int), 1, f) == 1 && std::fread(&nnz, sizeof(int), 1, f) == 1 &&
+              std::fread(&inSz, sizeof(int), 1, f) == 1 && std::fread(&outSz, sizeof(int), 1, f) == 1;
+    if (!ok || rows != N || cols != N) { std::fclose(f); return 0; }
+    SpMat m;
+    m.resize(rows, cols);
+    m.makeCompressed();
+    m.resizeNonZeros(nnz);
+    ok = std::fread(m.valuePtr(), sizeof(float), nnz, f) == (size_t)nnz && std::fread(m.outerIndexPtr(), sizeof(int), outSz, f) == (size_t)outSz &&
+         std::fread(m.innerIndexPtr(), sizeof(int), nnz, f) == (size_t)nnz;
+    std::fclose(f);
+    if (!ok) return 0;
+    m.finalize();
+    for (long k = 0; k < (long)N * N; k++) dense[k] = 0.0f;
+    for (int c = 0; c < m.outerSize(); ++c)
+        for (SpMat::InnerIterator it(m, c); it; ++it) dense[(long)it.row() * N + it.col()] = it.value();
     return 1;
 }
 

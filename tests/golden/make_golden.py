@@ -3,7 +3,7 @@ and Eigen 3.2.10 (oracle/_ref/libref_check.so, built by oracle/Makefile from
 /root/reference/libraries where they lie).  Fixtures are data only: inputs + the values the
 reference's own math libraries produce at the hot path's call sites.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [core display host obj fcache scenes]
 """
 import os
 import sys
@@ -249,22 +249,6 @@ def obj_loader():
     print("example scenes: host-loader fixtures equal tinyobj's arrays")
 
 
-if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "obj":
-        obj_loader()
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "host":
-        host_surface()
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "display":
-        display()
-        sys.exit(0)
-    main()
-    display()
-    host_surface()
-    obj_loader()
-
-
 def reference_scenes():
     """The reference's two example scenes (data files under /root/reference/example_scenes) parsed by
     the C++ host loader and stored as arrays, so that BASELINE.json's configs 0 and 1 can be run
@@ -291,5 +275,29 @@ def reference_scenes():
         print(name, got["tri_v"].shape[0], "triangles")
 
 
-if __name__ == "__main__" and os.path.isdir("/root/reference/example_scenes"):
-    reference_scenes()
+
+
+def fcache():
+    """the F-matrix disk cache written by SerializeMat's call sequence on the reference's Eigen (oracle/_ref)"""
+    import tempfile
+    assert ob.ref_available()
+    rs = np.random.RandomState(23)
+    N = 37
+    dense = np.where(rs.random_sample((N, N)) < 0.3, rs.random_sample((N, N)), 0).astype(np.float32)
+    dense[:, 5] = 0          # an empty column, an empty row, the last column empty: the outer-index edge cases
+    dense[11, :] = 0
+    dense[:, N - 1] = 0
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "mat.bin")
+        assert ob.ref_fcache_write(p, dense) == 1
+        raw = np.frombuffer(open(p, "rb").read(), np.uint8)
+        assert np.array_equal(ob.ref_fcache_read(p, N), dense)
+    np.savez_compressed(os.path.join(OUT, "fcache_eigen.npz"), dense=dense, file_bytes=raw)
+    print("wrote fcache_eigen.npz:", raw.size, "bytes,", int((dense != 0).sum()), "non-zeros")
+
+
+if __name__ == "__main__":
+    # python tests/golden/make_golden.py [core display host obj fcache scenes]   (default: all)
+    parts = {"core": main, "display": display, "host": host_surface, "obj": obj_loader, "fcache": fcache, "scenes": reference_scenes}
+    for part in (sys.argv[1:] or list(parts)):
+        parts[part]()

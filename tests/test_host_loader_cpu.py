@@ -275,3 +275,25 @@ def test_obj_mtl_parsing_equals_the_vendored_tinyobjloader(host, tmp_path):
                 for k in ("vertices", "normals", "tri_v", "tri_n", "mat"):
                     assert np.array_equal(t[k], mine[k]), (name, k)
                 assert np.array_equal(t["Kd"], mine["rgb"])
+
+
+def test_f_matrix_cache_format_equals_eigens(host, tmp_path):
+    """the file SerializeMat writes (vs/Lightning.h:21-45; bytes produced by that call sequence on the reference's
+    Eigen, tests/golden/make_golden.py fcache): the host reads it, and writes the same bytes for the same matrix"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fcache_eigen.npz"))
+    dense = np.ascontiguousarray(g["dense"], np.float32)
+    N = dense.shape[0]
+    host.drh_fcache_write.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+    host.drh_fcache_read.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+    ref_file = tmp_path / "eigen.bin"
+    ref_file.write_bytes(g["file_bytes"].tobytes())
+    got = np.zeros((N, N), np.float32)
+    assert host.drh_fcache_read(str(ref_file).encode(), N, got.ctypes.data_as(C.c_void_p)) == 1
+    assert np.array_equal(got, dense)
+    mine = tmp_path / "mine.bin"
+    assert host.drh_fcache_write(str(mine).encode(), N, dense.ctypes.data_as(C.c_void_p)) == 1
+    assert mine.read_bytes() == ref_file.read_bytes()
+    assert host.drh_fcache_read(str(ref_file).encode(), N + 1, got.ctypes.data_as(C.c_void_p)) == 0      # wrong size: refused
+    from oracle import binding as ob
+    if ob.ref_available():
+        assert np.array_equal(ob.ref_fcache_read(str(mine), N), dense)      # and Eigen reads the host's file
