@@ -148,6 +148,8 @@ public:
             }
         }
         chk(dr_solver_init(ctx_, S_, E.data(), M.data(), n_mat, mesh.materialIndexPerTriangle.data()), "dr_solver_init");
+        // RadMat is sparse in the reference; here the all-zero blocks of the dense matrix are not read (same bits out)
+        chk(dr_solver_skip_zero_blocks(ctx_, 1), "dr_solver_skip_zero_blocks");
         B_.assign((size_t)N_ * S_, 0.0f);
         refresh();
         numpasses_ = 0;
