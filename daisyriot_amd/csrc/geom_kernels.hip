@@ -428,8 +428,8 @@ __device__ __forceinline__ void integrand_pair(const float* ri, const float* rj,
 }
 
 // Walk of the threaded BVH for one wave of rays (segments [0,tmax] from org along dn); returns the
-// liveness mask with every lane cleared whose closest hit is not its destination `hi` (wave-uniform
-// int in the one-pair-per-wave path, per-lane int in the packed path).
+// liveness mask with every lane cleared whose closest hit is not its destination `hi` (wave-uniform: one pair
+// per wave).
 //
 // The node index is wave-uniform.  The compiler's lowering of this loop spent ~20 scalar instructions per
 // node (the CU's single scalar unit serves all four SIMDs) beside the vector ones, so the interior-node
@@ -439,9 +439,9 @@ __device__ __forceinline__ void integrand_pair(const float* ri, const float* rj,
 // 7 scalar instructions for a node that is entered, 6 for one that is skipped.  There is no end-of-tree
 // compare: skips that leave the tree land on the sentinel node (all-space box, leaf code BVH_END), which
 // every live lane hits; the hand-written stretch ends whenever a hit node is a leaf.
-template <bool STATS, typename HiT>
+template <bool STATS>
 __device__ __forceinline__ unsigned long long walk_bvh(const BvhNode* __restrict__ bvh, const TriRec* __restrict__ tri_sorted,
-                                                       int n_nodes_i, f3 org, f3 dn, f3 inv, float tmax, HiT hi,
+                                                       int n_nodes_i, f3 org, f3 dn, f3 inv, float tmax, int hi,
                                                        unsigned long long alive_m, int& n_visit, int& n_leaf) {
     if (alive_m == 0ull) return 0ull;
     // per-ray constants of the node test
