@@ -35,7 +35,7 @@ struct TriRec {
 struct BvhNode {
     float c[3], h[3];
     int   skip;
-    int   tri;          // leaf: first*8 + (count-1) into the Morton-ordered TriRec array; -1: internal
+    int   tri;          // leaf: first*8 + (count-1) [+4: both triangles have the same gate box] into the Morton-ordered TriRecs; -1: internal
 };                      // 32 B: one s_load_dwordx8
 constexpr int BVH_END = 0x7ffffff8;
 

@@ -217,7 +217,7 @@ __global__ void k_refit(int N, const TriRec* __restrict__ tri, const int* __rest
 __global__ void k_emit(int N, const int* __restrict__ left, const int* __restrict__ first,
                        const int* __restrict__ last, const int* __restrict__ parent,
                        const float* __restrict__ box, const int* __restrict__ esize, float node_pad,
-                       BvhNode* __restrict__ nodes) {
+                       const TriRec* __restrict__ tri_sorted, BvhNode* __restrict__ nodes) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= 2 * N - 1) return;
     const bool internal = id < N - 1;
@@ -243,6 +243,13 @@ __global__ void k_emit(int N, const int* __restrict__ left, const int* __restric
     }
     nd.skip = (idx + esize[id]) * (int)sizeof(BvhNode);
     nd.tri = (cnt <= LEAF_MAX) ? f * 8 + (cnt - 1) : -1;
+    if (cnt == 2) {
+        // the two triangles of a quad have the same gate box: flag it, the walk then tests that box once
+        const TriRec &t0 = tri_sorted[f], &t1 = tri_sorted[f + 1];
+        bool same = true;
+        for (int a = 0; a < 3; a++) same = same && (t0.lo[a] == t1.lo[a]) && (t0.hi[a] == t1.hi[a]);
+        if (same) nd.tri |= 4;
+    }
     nodes[idx] = nd;
 }
 
@@ -297,7 +304,7 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
         DR_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_pad_tris, dim3(1), dim3(64), 0, st, N, tri_sorted);
         DR_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_emit, dim3((int)((nn + 255) / 256)), dim3(256), 0, st, N, left, first, last, parent, box, esize, node_pad, nodes);
+        hipLaunchKernelGGL(k_emit, dim3((int)((nn + 255) / 256)), dim3(256), 0, st, N, left, first, last, parent, box, esize, node_pad, tri_sorted, nodes);
         DR_TRY(hipGetLastError());
         // nodes written = size of the root's subtree (a lone triangle is its own root leaf)
         DR_TRY(hipMemcpyAsync(n_nodes_out, esize, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -533,23 +540,27 @@ __device__ __forceinline__ unsigned long long walk_bvh(const BvhNode* __restrict
         }
         if (leaf == BVH_END) break;
         if (STATS) n_leaf++;
-        const int first = leaf >> 3, cnt = (leaf & 7) + 1;
+        const int first = leaf >> 3, cnt = (leaf & 3) + 1;
+        const bool same_gate = (leaf & 4) != 0;          // both triangles share one gate box (the halves of a quad)
         // Leaf: its LEAF_MAX records (64 B each: triangle, id, gate box) are fetched together --
         // no dependent loads inside the leaf; a triangle's Moller-Trumbore test only runs when some
-        // live lane passes its gate.  The destination itself needs no exclusion: its t equals tmax
-        // bit for bit and its id is not lower than its own.
+        // live lane passes its gate.
         const v4f* tp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(tri_sorted) + (unsigned)first * 64u);
         v4f q[4 * LEAF_MAX];
 #pragma unroll
         for (int c = 0; c < 4 * LEAF_MAX; c++) q[c] = tp[c];
-        unsigned long long blocked_m = 0ull;
+        unsigned long long blocked_m = 0ull, gm_prev = 0ull;
 #pragma unroll
         for (int c = 0; c < LEAF_MAX; c++) {
             const v4f A = q[4 * c], B = q[4 * c + 1], C3 = q[4 * c + 2], D = q[4 * c + 3];
             const float blo[3] = { C3[2], C3[3], D[0] }, bhi[3] = { D[1], D[2], D[3] };
-            const unsigned long long gm = box_hit_mask(blo, bhi, org, inv, tmax) & alive_m;
+            unsigned long long gm;
+            if (c == 1 && same_gate) gm = gm_prev;     // bit-identical box: the same mask
+            else gm = box_hit_mask(blo, bhi, org, inv, tmax) & alive_m;
+            gm_prev = gm;
             if (gm == 0ull || c >= cnt) continue;      // (slots past the leaf's count belong to the next leaf)
             const int tk = __builtin_amdgcn_readfirstlane(__float_as_int(C3[1]));
+            if (tk == hi) continue;                    // the destination: its t is tmax bit for bit, it never precedes itself
             const f3 ta = f3{ A[0], A[1], A[2] };
             const f3 te1 = f3{ A[3], B[0], B[1] };
             const f3 te2 = f3{ B[2], B[3], C3[0] };

@@ -252,7 +252,7 @@ def test_bvh_invariants():
     n = len(b)
     assert np.all(b["skip"] > np.arange(n)) and np.all(b["skip"] <= n) and b["skip"][0] == n
     leaf = b["tri"] >= 0
-    first, cnt = b["tri"][leaf] >> 3, (b["tri"][leaf] & 7) + 1
+    first, cnt = b["tri"][leaf] >> 3, (b["tri"][leaf] & 3) + 1          # (bit 2: the leaf's two gate boxes are equal)
     assert cnt.sum() == sc.N and cnt.max() <= 4
     order = np.argsort(first)
     assert np.array_equal(first[order], np.r_[0, np.cumsum(cnt[order])[:-1]])     # leaves tile the sorted array
