@@ -59,6 +59,14 @@ def cpu_baselines(ctx, sc, uv, n_rows_sweep, n_rows_ff):
 
     N, S = sc.N, sc.S
     info = ctx.info()
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     r0 = info.row0
     _, R = ctx.read(B=False, R=True)
     # a 256-row probe sizes the sample to about 10 s of single-thread work
@@ -76,7 +84,7 @@ def cpu_baselines(ctx, sc, uv, n_rows_sweep, n_rows_ff):
         ob.sweep_rows(F, sc.M, sc.mat_of_patch, R, B, row0=r0, threads=1)
         dt = time.perf_counter() - t
     iters = 1.0 / (dt * (N / n1))
-    sweep = {"value": iters, "unit": "iters/s", "cores": 1, "kind": "port",
+    sweep = {"value": iters, "unit": "iters/s", "cores": 1, "kind": "port", "cpu": cpu_model,
              "sample": "%d of %d rows of the same F and residual, all %d bins, oracle/orc_sweep_rows, %.1f s"
                        % (n1, N, S, dt)}
     n2 = min(n_rows_ff, info.nrows)
@@ -98,7 +106,7 @@ def cpu_baselines(ctx, sc, uv, n_rows_sweep, n_rows_ff):
     t = time.perf_counter()
     ob.assemble_rows(m, uv, row0=r0, nrows=n3, want_vis=False, threads=cores, bvh=True)
     dt4 = time.perf_counter() - t
-    allcores = {"cores": cores, "kind": "port", "iters_per_s": 1.0 / (dt3 * (N / n1)),
+    allcores = {"cores": cores, "kind": "port", "cpu": cpu_model, "iters_per_s": 1.0 / (dt3 * (N / n1)),
                 "pairs_per_s": n3 * (N - 1) / dt4,
                 "sample": "same row samples (%d sweep rows, %d assembly rows), OpenMP over rows, %.1f + %.1f s" % (n1, n3, dt3, dt4)}
     return sweep, ff, allcores
