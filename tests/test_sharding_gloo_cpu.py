@@ -74,3 +74,72 @@ def test_row_sharded_passes_equal_unsharded(world, tmp_path):
         Rr = np.load(tmp_path / ("R_%d.npy" % r))
         assert np.array_equal(Rr.view(np.uint32), R.view(np.uint32)), "rank %d holds a different residual" % r
     assert np.array_equal(np.concatenate(Bs).view(np.uint32), B.view(np.uint32))
+
+
+def _assembly_rank_main(rank, world, port, N, out_dir):
+    """the ray-count exchange of a multi-rank assembly over a real collective: every tile pair between two ranks' rows
+    is 'traced' (here: taken from the oracle) by the rank dr_vis_exchange_tracer names, its 64 x 64 counts go to slot
+    (own tile, foreign tile) of the rank's chunk, one all-gather, and the other rank picks slot (foreign, own)"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = scenes.cornell_box(N, S=3)
+    uv = scenes.visibility_samples(50)
+    row0, nrows, rpr = api.shard_rows(sc.N, rank, world)
+    m = ob.Mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+    T, nT = rpr // 64, (sc.N + 63) // 64
+    # what this rank may look at: the counts of its own rows (it could trace any pair that touches them)
+    _, Vown, _ = ob.assemble_rows(m, uv, row0=row0, nrows=nrows, bvh=True, want_vis=True)
+
+    def tile(V_rows, o, t):                 # counts of own tile o x tile t, rows = the tile of the lower index
+        blk = np.full((64, 64), 255, np.uint8)
+        r0, c0 = o * 64 - row0, t * 64
+        sub = V_rows[r0:r0 + 64, c0:c0 + 64]
+        blk[:sub.shape[0], :sub.shape[1]] = sub
+        return blk if o < t else blk.T
+
+    chunk = np.full((T, nT, 64, 64), 255, np.uint8)
+    own_tiles = range(row0 // 64, (row0 + nrows + 63) // 64)
+    traced = 0
+    for o in own_tiles:
+        for t in range(nT):
+            if t // T == rank:
+                continue
+            if api.vis_exchange_tracer(sc.N, world, o * 64, t * 64) == rank:
+                chunk[o - rank * T, t] = tile(Vown, o, t)
+                traced += 1
+    gathered = torch.zeros(world * chunk.size, dtype=torch.uint8)
+    dist.all_gather_into_tensor(gathered, torch.from_numpy(chunk.reshape(-1)))
+    G = gathered.numpy().reshape(world * T, nT, 64, 64)
+    # rebuild the counts of the own rows: own x own and own-traced pairs locally, the rest from the slots
+    V = np.full((nrows, sc.N), 255, np.uint8)
+    for o in own_tiles:
+        for t in range(nT):
+            mine = (t // T == rank) or api.vis_exchange_tracer(sc.N, world, o * 64, t * 64) == rank
+            blk = tile(Vown, o, t) if mine else G[t, o]
+            blk = blk if o < t else blk.T       # back to rows = this rank's tile
+            r0, c0 = o * 64 - row0, t * 64
+            h, w = min(64, nrows - r0), min(64, sc.N - c0)
+            V[r0:r0 + h, c0:c0 + w] = blk[:h, :w]
+    np.save(os.path.join(out_dir, "V_%d.npy" % rank), V)
+    np.save(os.path.join(out_dir, "n_%d.npy" % rank), np.array([traced]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ray_count_exchange_protocol_over_a_collective(world, tmp_path):
+    N = 700
+    mp.spawn(_assembly_rank_main, args=(world, _free_port(), N, str(tmp_path)), nprocs=world, join=True)
+    sc = scenes.cornell_box(N, S=3)
+    m = ob.Mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+    _, V, _ = ob.assemble_rows(m, scenes.visibility_samples(50), bvh=True, want_vis=True)
+    n_cross = 0
+    for r in range(world):
+        row0, nrows, rpr = api.shard_rows(N, r, world)
+        assert np.array_equal(np.load(tmp_path / ("V_%d.npy" % r)), V[row0:row0 + nrows]), r
+        n_cross += int(np.load(tmp_path / ("n_%d.npy" % r))[0])
+    # every tile pair between two different ranks was traced exactly once
+    T = api.shard_rows(N, 0, world)[2] // 64
+    nT = (N + 63) // 64
+    want = sum(1 for a in range(nT) for b in range(a + 1, nT) if a // T != b // T)
+    assert n_cross == want
