@@ -646,3 +646,30 @@ def test_zero_block_skipping_is_bit_identical(S, n, world, rank, uv50):
         c.step(1)
         Bd, _ = c.read(R=False)
         assert np.array_equal(_bits(Bs[row0:row0 + nrows]), _bits(Bd[row0:row0 + nrows]))
+
+
+def test_work_on_the_callers_stream(uv50):
+    """dr_set_stream: launches and copies go to a stream the host owns (here a torch stream), so that the host can
+    order its own work with ours; results as on the context's own stream; back to the own stream with NULL"""
+    import torch
+    sc = scenes.cornell_box(900, S=8, fluorescent=True)
+    E = sc.emission(7.0)
+    with _ctx(sc) as c:
+        c.assemble(uv50)
+        c.solver_init(E, sc.M, sc.mat_of_patch)
+        c.step(3)
+        B0, R0 = c.read()
+    st = torch.cuda.Stream()
+    with api.Context(0) as c:
+        c.set_stream(st.cuda_stream)
+        c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+        c.assemble(uv50)
+        c.solver_init(E, sc.M, sc.mat_of_patch)
+        c.step(2)
+        done = torch.cuda.Event()
+        done.record(st)                      # the host's own marker behind our passes on its stream
+        done.synchronize()
+        c.set_stream(0)                      # NULL: back to the context's stream (drains the other one first)
+        c.step(1)
+        B1, R1 = c.read()
+    assert np.array_equal(_bits(B1), _bits(B0)) and np.array_equal(_bits(R1), _bits(R0))
