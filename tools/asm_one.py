@@ -1,0 +1,12 @@
+import sys, os, time
+sys.path.insert(0, '.')
+import numpy as np
+from daisyriot_amd import api, scenes
+N = int(os.environ.get("NPATCH", "16384"))
+sc = scenes.cornell_box(N, S=8)
+uv = scenes.visibility_samples(50)
+c = api.Context(0)
+c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+c.assemble(uv)
+i = c.info()
+print("RES", N, "ms", round(i.last_assemble_ms,1), "traced", i.pairs_traced, flush=True)
