@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cctype>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 
@@ -22,14 +23,17 @@ std::string lstrip(const std::string& s) {
     while (i < s.size() && std::isspace((unsigned char)s[i])) i++;
     return s.substr(i);
 }
-// an inline comment starts at a ';' that follows whitespace
-std::string cut_inline_comment(const std::string& s) {
-    bool prev_space = false;
-    for (size_t i = 0; i < s.size(); i++) {
-        if (s[i] == ';' && prev_space) return s.substr(0, i);
-        prev_space = std::isspace((unsigned char)s[i]) != 0;
+// position of the first character of `stops` in s[from..], or of an inline comment -- a ';' that follows a
+// whitespace character seen since `from` -- whichever comes first; s.size() if neither (the scan the reference's
+// parser applies to section lines, names and values alike)
+size_t scan(const std::string& s, size_t from, const char* stops) {
+    bool was_space = false;
+    for (size_t i = from; i < s.size(); i++) {
+        if (stops && std::strchr(stops, s[i])) return i;
+        if (was_space && s[i] == ';') return i;
+        was_space = std::isspace((unsigned char)s[i]) != 0;
     }
-    return s;
+    return s.size();
 }
 
 }  // namespace
@@ -48,43 +52,48 @@ INIReader INIReader::FromString(const std::string& text) {
     return r;
 }
 
+// Same line grammar as the parser inside the reference's INIReader.h (its compile-time options: multi-line values,
+// BOM, inline ';' comments after whitespace, no stop at the first error; names and sections kept to 49 characters where
+// that parser copies them into fixed buffers): full-line comments (';' or '#') first, then continuation lines (leading
+// whitespace while a name is current), then [section], then name[=:]value.  Not mirrored: its 199-character line buffer.
 void INIReader::parse(std::istream& in) {
     std::string line, section, prev_name;
     int lineno = 0;
-    bool first = true;
+    auto store = [&](const std::string& name, const std::string& value) {
+        std::string& slot = values_[key(section, name)];
+        if (!slot.empty()) slot += "\n";                // repeated keys and continuation lines accumulate
+        slot += value;
+        sections_.insert(section);
+    };
     while (std::getline(in, line)) {
         lineno++;
-        if (first) {        // UTF-8 byte order mark
-            first = false;
-            if (line.size() >= 3 && (unsigned char)line[0] == 0xEF && (unsigned char)line[1] == 0xBB && (unsigned char)line[2] == 0xBF)
-                line = line.substr(3);
-        }
+        if (lineno == 1 && line.size() >= 3 && (unsigned char)line[0] == 0xEF && (unsigned char)line[1] == 0xBB &&
+            (unsigned char)line[2] == 0xBF)
+            line = line.substr(3);                       // UTF-8 byte order mark
         const bool led_by_space = !line.empty() && std::isspace((unsigned char)line[0]);
-        std::string s = rstrip(lstrip(line));
-        if (s.empty() || s[0] == ';' || s[0] == '#') continue;
-        if (led_by_space && !prev_name.empty()) {       // continuation of the previous value
-            std::string& v = values_[key(section, prev_name)];
-            v += "\n";
-            v += rstrip(cut_inline_comment(s));
+        std::string s = lstrip(rstrip(line));
+        if (s.empty()) continue;
+        if (s[0] == ';' || s[0] == '#') continue;
+        if (led_by_space && !prev_name.empty()) {       // continuation of the previous name's value
+            store(prev_name, rstrip(s.substr(0, scan(s, 0, nullptr))));
             continue;
         }
         if (s[0] == '[') {
-            size_t end = s.find(']');
-            if (end == std::string::npos) { if (!error_) error_ = lineno; continue; }
-            section = s.substr(1, end - 1);
-            sections_.insert(section);
-            prev_name.clear();
+            const size_t end = scan(s, 1, "]");
+            if (end < s.size() && s[end] == ']') {
+                section = s.substr(1, end - 1).substr(0, 49);
+                prev_name.clear();
+            } else if (!error_) error_ = lineno;
             continue;
         }
-        size_t sep = s.find_first_of("=:");
-        if (sep == std::string::npos) { if (!error_) error_ = lineno; continue; }
-        std::string name = rstrip(s.substr(0, sep));
-        std::string value = rstrip(lstrip(cut_inline_comment(s.substr(sep + 1))));
-        std::string& slot = values_[key(section, name)];
-        if (!slot.empty()) slot += "\n";                // repeated keys accumulate
-        slot += value;
-        sections_.insert(section);
-        prev_name = name;
+        const size_t sep = scan(s, 0, "=:");
+        if (sep < s.size() && (s[sep] == '=' || s[sep] == ':')) {
+            const std::string name = rstrip(s.substr(0, sep));
+            std::string value = lstrip(s.substr(sep + 1));
+            value = rstrip(value.substr(0, scan(value, 0, nullptr)));
+            prev_name = name.substr(0, 49);
+            store(name, value);
+        } else if (!error_) error_ = lineno;
     }
 }
 

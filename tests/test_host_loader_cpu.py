@@ -297,3 +297,38 @@ def test_f_matrix_cache_format_equals_eigens(host, tmp_path):
     from oracle import binding as ob
     if ob.ref_available():
         assert np.array_equal(ob.ref_fcache_read(str(mine), N), dense)      # and Eigen reads the host's file
+
+
+def test_ini_reader_fuzz_against_the_reference_inireader(host, tmp_path):
+    """random ini texts (sections, ':' and '=' separators, inline and full-line comments, continuation lines, empty
+    values, duplicate keys, malformed lines, CR line ends): every lookup and the error line number equal the reference's
+    own INIReader.h (live; needs the checker library oracle/_ref)"""
+    import random
+    from oracle import binding as ob
+    if not ob.ref_available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    rnd = random.Random(7)
+    secs = ["a", "B", "window", "Sec Tion", "x.y"]
+    names = ["k", "Key", "width", "v a l", "n1", "on", "x"]
+    vals = ["1", "0", "true", "False", "yes", "no", "on", "off", "0x1F", "-3", "4.5e2", "abc", "a b c", "  padded  ", "", "7 ; c",
+            "8 # c", "\"q\"", "1,2", "TRUE", "On"]
+
+    def line():
+        r = rnd.random()
+        if r < 0.18:
+            return "[%s]%s" % (rnd.choice(secs), rnd.choice(["", " ", "  ; c", "\t# c"]))
+        if r < 0.26:
+            return rnd.choice(["; comment", "# comment", "", "   ", "\t"])
+        if r < 0.32:
+            return rnd.choice(["no separator here", "[unclosed", "  continuation text", "= novalue name", " [a]", "[a ;c]", "k ;c = 1"])
+        sep = rnd.choice(["=", ":", " = ", " : ", "\t=\t"])
+        lead = rnd.choice(["", " ", "\t"]) if rnd.random() < 0.15 else ""
+        return "%s%s%s%s%s" % (lead, rnd.choice(names), sep, rnd.choice(vals), rnd.choice(["", " ", "\r", " ; tail"]))
+
+    queries = [(k, s, n, d) for s in secs + ["a ", "A"] for n in names + ["KEY"]
+               for k, d in (("get", "D"), ("integer", -9), ("real", -1.5), ("boolean", 1), ("boolean", 0))]
+    for it in range(300):
+        text = "\n".join(line() for _ in range(rnd.randint(3, 25))) + rnd.choice(["", "\n"])
+        p = tmp_path / ("f%d.ini" % it)
+        p.write_text(text)
+        assert _host_ini_query(host, str(p), queries) == ob.ref_ini_query(str(p), queries), text
