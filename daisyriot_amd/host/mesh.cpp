@@ -3,6 +3,7 @@
 // classification of MeshS.cpp:36-66 / Material.cpp:6-100.
 #include "mesh.h"
 
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -127,108 +128,198 @@ MeshS::MeshS(const char* filepath, const char* mtlpath, const std::vector<float>
 
 namespace {
 
-struct MtlEntry { std::string name; vec3 Kd{ 0.6f, 0.6f, 0.6f }, Ks{ 0, 0, 0 }, Ke{ 0, 0, 0 }; };
+struct MtlEntry { std::string name; vec3 Kd{ 0, 0, 0 }, Ks{ 0, 0, 0 }, Ke{ 0, 0, 0 }; };      // the parser's defaults are 0
 
-bool read_vec3(std::istringstream& is, vec3& v) {
-    float a = 0, b = 0, c = 0;
-    if (!(is >> a)) return false;
-    if (!(is >> b)) { b = a; c = a; } else if (!(is >> c)) c = 0;
-    v = vec3{ a, b, c };
-    return true;
+// A number as the reference's OBJ parser (tinyobjloader, vendored) reads it -- its own grammar and arithmetic, not
+// strtod's, and the vertex coordinates of a scene must come out bit for bit the same: [+-]digits[.digits][e[+-]digits];
+// a sign must be followed by a digit (".5" and "-.5" are not numbers: the default, 0); the integer part is accumulated
+// digit by digit in double, each decimal digit is added times 10^-k (the first seven powers from a table of double
+// literals), a non-zero exponent e is applied as ldexp(mantissa * 5^e, e); anything after the number is ignored.
+float parse_real(const std::string& tok, double def = 0.0) {
+    const char *s = tok.c_str(), *end = s + tok.size();
+    if (s >= end) return (float)def;
+    double mantissa = 0.0;
+    int exponent = 0, read = 0;
+    char sign = '+', exp_sign = '+';
+    auto digit = [](char c) { return c >= '0' && c <= '9'; };
+    if (*s == '+' || *s == '-') { sign = *s; s++; }
+    else if (!digit(*s)) return (float)def;
+    while (s != end && digit(*s)) { mantissa *= 10; mantissa += (int)(*s - '0'); s++; read++; }
+    if (read == 0) return (float)def;
+    bool done = (s == end);
+    if (!done) {
+        if (*s == '.') {
+            s++;
+            read = 1;
+            static const double pow_lut[] = { 1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001 };
+            while (s != end && digit(*s)) {
+                mantissa += (int)(*s - '0') * (read < 8 ? pow_lut[read] : std::pow(10.0, -read));
+                read++; s++;
+            }
+        } else if (*s != 'e' && *s != 'E') done = true;
+    }
+    if (!done && s != end && (*s == 'e' || *s == 'E')) {
+        s++;
+        if (s != end && (*s == '+' || *s == '-')) { exp_sign = *s; s++; }
+        else if (s == end || !digit(*s)) return (float)def;             // an empty exponent is not a number
+        read = 0;
+        while (s != end && digit(*s)) { exponent *= 10; exponent += (int)(*s - '0'); s++; read++; }
+        exponent *= (exp_sign == '+' ? 1 : -1);
+        if (read == 0) return (float)def;
+    }
+    const double v = (sign == '+' ? 1 : -1) * (exponent ? std::ldexp(mantissa * std::pow(5.0, exponent), exponent) : mantissa);
+    return (float)v;
 }
 
-void load_mtl(const std::string& path, std::vector<MtlEntry>& out, std::string& warn) {
+bool is_blank(char c) { return c == ' ' || c == '\t'; }
+
+// first whitespace-delimited word at p (what sscanf("%s") takes)
+std::string word_at(const char* p) {
+    while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n' || *p == '\v' || *p == '\f') p++;
+    const char* e = p;
+    while (*e && !std::isspace((unsigned char)*e)) e++;
+    return std::string(p, e);
+}
+
+// up to three numbers from p on, missing ones 0 (each token ends at a blank or CR)
+void read3(const char* p, vec3& v) {
+    float out[3] = { 0, 0, 0 };
+    for (int k = 0; k < 3; k++) {
+        while (is_blank(*p)) p++;
+        const char* e = p;
+        while (*e && *e != ' ' && *e != '\t' && *e != '\r') e++;
+        out[k] = parse_real(std::string(p, e));
+        p = e;
+    }
+    v = vec3{ out[0], out[1], out[2] };
+}
+
+// The .mtl grammar of the reference's parser: a statement is recognised by its keyword followed by a blank; colours take
+// up to three numbers (missing ones 0, no statement: 0); a file without any `newmtl` still yields one unnamed material;
+// of two materials with one name both are kept and `usemtl` finds the first.  Returns false if the file cannot be opened.
+bool load_mtl(const std::string& path, std::vector<MtlEntry>& out, std::map<std::string, int>& index, std::string& warn) {
     std::ifstream f(path.c_str());
-    if (!f.is_open()) { warn += "material file not found: " + path + "\n"; return; }
+    if (!f.is_open()) { warn += "material file not found: " + path + "\n"; return false; }
+    MtlEntry cur;
     std::string line;
+    auto flush = [&]() {
+        index.insert({ cur.name, (int)out.size() });
+        out.push_back(cur);
+    };
     while (std::getline(f, line)) {
-        std::istringstream is(line);
-        std::string tok;
-        if (!(is >> tok) || tok[0] == '#') continue;
-        if (tok == "newmtl") { MtlEntry e; is >> e.name; out.push_back(e); }
-        else if (out.empty()) continue;
-        else if (tok == "Kd") read_vec3(is, out.back().Kd);
-        else if (tok == "Ks") read_vec3(is, out.back().Ks);
-        else if (tok == "Ke") read_vec3(is, out.back().Ke);
+        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) { line.pop_back(); break; }
+        const char* t = line.c_str();
+        while (is_blank(*t)) t++;
+        if (*t == '\0' || *t == '#') continue;
+        if (std::strncmp(t, "newmtl", 6) == 0 && is_blank(t[6])) {
+            if (!cur.name.empty()) flush();
+            cur = MtlEntry();
+            cur.name = word_at(t + 7);
+        } else if (t[0] == 'K' && t[1] == 'd' && is_blank(t[2])) read3(t + 2, cur.Kd);
+        else if (t[0] == 'K' && t[1] == 's' && is_blank(t[2])) read3(t + 2, cur.Ks);
+        else if (t[0] == 'K' && t[1] == 'e' && is_blank(t[2])) read3(t + 2, cur.Ke);
     }
-}
-
-// one "v", "v/t", "v//n" or "v/t/n" corner; negative indices count from the end (OBJ spec)
-bool parse_corner(const std::string& tok, int nv, int nn, int& vi, int& ni) {
-    vi = ni = -1;
-    const char* s = tok.c_str();
-    char* e = nullptr;
-    long a = std::strtol(s, &e, 10);
-    if (e == s) return false;
-    vi = a > 0 ? (int)a - 1 : nv + (int)a;
-    if (*e == '/') {
-        e++;
-        if (*e != '/') std::strtol(e, &e, 10);                // texture index, unused
-        if (*e == '/') {
-            e++;
-            const char* s2 = e;
-            long c = std::strtol(s2, &e, 10);
-            if (e != s2) ni = c > 0 ? (int)c - 1 : nn + (int)c;
-        }
-    }
+    flush();
     return true;
 }
+
+int fix_index(int idx, int n) { return idx > 0 ? idx - 1 : (idx == 0 ? 0 : n + idx); }      // 1-based, negative = from the end
 
 }  // namespace
 
+// The OBJ grammar and -- because the arrays must come out as the reference's parser (tinyobjloader, called with
+// triangulate = false, MeshS.cpp:25-31) delivers them -- its bookkeeping: faces collect in a group that is moved into
+// the current shape whenever `usemtl` changes the material; `g` and `o` close the shape, and keep it only if the group
+// was not empty at that moment (faces moved out by an earlier `usemtl` are lost with it -- a quirk the reference
+// inherits); the end of the file keeps the shape if it holds anything; of several `mtllib` names only the first file
+// that opens is read.
 void MeshS::loadFromFile(const char* filepath, const char* mtldir, const std::vector<float>& wl) {
     *this = MeshS();
     std::ifstream f(filepath);
     if (!f.is_open()) { warnings += std::string("cannot open ") + filepath + "\n"; return; }
     std::string dir = mtldir ? mtldir : "";
+    // (the reference's parser glues directory and file name together as they are; a directory given without its
+    // trailing separator finds no material file there and the viewer then indexes an empty material list)
     if (!dir.empty() && dir.back() != '/' && dir.back() != '\\') dir += "/";
 
+    struct Face { std::vector<std::pair<int, int>> c; int mat; };
     std::vector<MtlEntry> mtl;
     std::map<std::string, int> mtl_index;
-    std::vector<int> face_mat;
+    std::vector<std::vector<std::pair<int, int>>> group;      // faces since the last flush
+    std::vector<Face> shape, kept;
     int cur_mat = -1;
+    auto flush_group = [&]() {
+        const bool any = !group.empty();
+        for (auto& c : group) shape.push_back(Face{ std::move(c), cur_mat });
+        group.clear();
+        return any;
+    };
     bool polygon_warned = false, normal_warned = false;
     std::string line;
     while (std::getline(f, line)) {
-        std::istringstream is(line);
-        std::string tok;
-        if (!(is >> tok) || tok[0] == '#') continue;
-        if (tok == "v") { vec3 v{ 0, 0, 0 }; is >> v.x >> v.y >> v.z; vertices.push_back(v); }
-        else if (tok == "vn") { vec3 v{ 0, 0, 0 }; is >> v.x >> v.y >> v.z; normals.push_back(v); }
-        else if (tok == "mtllib") {
-            std::string name;
-            while (is >> name) {
-                size_t before = mtl.size();
-                load_mtl(dir + name, mtl, warnings);
-                for (size_t k = before; k < mtl.size(); k++) mtl_index[mtl[k].name] = (int)k;
-            }
-        } else if (tok == "usemtl") {
-            std::string name;
-            is >> name;
-            auto it = mtl_index.find(name);
-            cur_mat = it == mtl_index.end() ? -1 : it->second;
-            if (it == mtl_index.end()) warnings += "unknown material " + name + "\n";
-        } else if (tok == "f") {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        const char* t = line.c_str();
+        while (is_blank(*t)) t++;
+        if (*t == '\0' || *t == '#') continue;
+        if (t[0] == 'v' && is_blank(t[1])) { vec3 v; read3(t + 2, v); vertices.push_back(v); }
+        else if (t[0] == 'v' && t[1] == 'n' && is_blank(t[2])) { vec3 v; read3(t + 3, v); normals.push_back(v); }
+        else if (t[0] == 'f' && is_blank(t[1])) {
+            const char* p = t + 2;
+            while (is_blank(*p)) p++;
             std::vector<std::pair<int, int>> c;
-            std::string ct;
-            while (is >> ct) {
-                int vi, ni;
-                if (parse_corner(ct, (int)vertices.size(), (int)normals.size(), vi, ni)) c.push_back({ vi, ni });
+            const int nv = (int)vertices.size(), nn = (int)normals.size();
+            while (*p && *p != '\r' && *p != '\n') {
+                // one corner: v, v/t, v//n or v/t/n; each number read like atoi, then skipped up to '/', blank or CR
+                int vi = fix_index(std::atoi(p), nv), ni = -1;
+                p += std::strcspn(p, "/ \t\r");
+                if (*p == '/') {
+                    p++;
+                    if (*p == '/') { p++; ni = fix_index(std::atoi(p), nn); p += std::strcspn(p, "/ \t\r"); }
+                    else {
+                        p += std::strcspn(p, "/ \t\r");           // texture index, unused
+                        if (*p == '/') { p++; ni = fix_index(std::atoi(p), nn); p += std::strcspn(p, "/ \t\r"); }
+                    }
+                }
+                c.push_back({ vi, ni });
+                p += std::strspn(p, " \t\r");
             }
-            if (c.size() < 3) continue;
-            if (c.size() > 3 && !polygon_warned) {
-                // the reference loads with triangulate=false and then reads indices three at a time,
-                // i.e. it silently assumes triangles; polygons are fan-triangulated here instead
-                warnings += "polygon faces were fan-triangulated\n";
-                polygon_warned = true;
+            group.push_back(std::move(c));
+        } else if (std::strncmp(t, "usemtl", 6) == 0 && is_blank(t[6])) {
+            const std::string name = word_at(t + 7);
+            auto it = mtl_index.find(name);
+            const int id = it == mtl_index.end() ? -1 : it->second;
+            if (it == mtl_index.end()) warnings += "unknown material " + name + "\n";
+            if (id != cur_mat) { flush_group(); cur_mat = id; }
+        } else if (std::strncmp(t, "mtllib", 6) == 0 && is_blank(t[6])) {
+            std::istringstream names(t + 7);
+            std::string name;
+            while (std::getline(names, name, ' ')) {
+                if (name.empty()) continue;
+                if (load_mtl(dir + name, mtl, mtl_index, warnings)) break;
             }
-            for (size_t k = 1; k + 1 < c.size(); k++) {
-                vertex::TriangleIndex t;
-                t.vertex = ivec3{ c[0].first, c[k].first, c[k + 1].first };
-                t.normal = ivec3{ c[0].second, c[k].second, c[k + 1].second };
-                triangleIndices.push_back(t);
-                face_mat.push_back(cur_mat);
-            }
+        } else if ((t[0] == 'g' || t[0] == 'o') && is_blank(t[1])) {
+            if (flush_group()) kept.insert(kept.end(), shape.begin(), shape.end());
+            shape.clear();
+        }
+    }
+    if (flush_group() || !shape.empty()) kept.insert(kept.end(), shape.begin(), shape.end());
+
+    std::vector<int> face_mat;
+    for (const Face& fc : kept) {
+        const auto& c = fc.c;
+        if (c.size() < 3) continue;
+        if (c.size() > 3 && !polygon_warned) {
+            // the reference loads with triangulate=false and then reads indices three at a time,
+            // i.e. it silently assumes triangles; polygons are fan-triangulated here instead
+            warnings += "polygon faces were fan-triangulated\n";
+            polygon_warned = true;
+        }
+        for (size_t k = 1; k + 1 < c.size(); k++) {
+            vertex::TriangleIndex tr;
+            tr.vertex = ivec3{ c[0].first, c[k].first, c[k + 1].first };
+            tr.normal = ivec3{ c[0].second, c[k].second, c[k + 1].second };
+            triangleIndices.push_back(tr);
+            face_mat.push_back(fc.mat);
         }
     }
 

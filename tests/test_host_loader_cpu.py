@@ -332,3 +332,58 @@ def test_ini_reader_fuzz_against_the_reference_inireader(host, tmp_path):
         p = tmp_path / ("f%d.ini" % it)
         p.write_text(text)
         assert _host_ini_query(host, str(p), queries) == ob.ref_ini_query(str(p), queries), text
+
+
+def _random_obj(rnd):
+    """triangles whose corners all carry a normal and whose materials exist (nothing for the loader to repair)"""
+    def fnum():
+        return rnd.choice(["%d" % rnd.randint(-3, 3), "%.3f" % rnd.uniform(-2, 2), "%.2e" % rnd.uniform(-2, 2), "-.5", ".25", "1.", "+2.5",
+                           "%.9f" % rnd.uniform(-1, 1), "%.7g" % rnd.uniform(-1e3, 1e3), "1e", "3e-2x", "12.5000001", "0.1", "-0.30000001"])
+    nv, nn, nt = rnd.randint(3, 9), rnd.randint(1, 4), rnd.randint(0, 3)
+    lines = ["mtllib m.mtl", "# c", "usemtl a"]
+    for _ in range(nv):
+        lines.append("v%s%s %s %s%s" % (rnd.choice([" ", "  ", "\t"]), fnum(), fnum(), fnum(), rnd.choice(["", " ", " 1.0"])))
+    for _ in range(nn):
+        lines.append("vn %s %s %s" % (fnum(), fnum(), fnum()))
+    for _ in range(nt):
+        lines.append("vt %s %s" % (fnum(), fnum()))
+    for _ in range(rnd.randint(1, 8)):
+        r = rnd.random()
+        if r < 0.15:
+            lines.append("usemtl " + rnd.choice(["a", "b"]))
+        elif r < 0.25:
+            lines.append(rnd.choice(["g grp", "o obj", "s off", "s 1", "", "# x", "g"]))
+        else:
+            def corner():
+                vi = rnd.randint(1, nv)
+                vi = vi if rnd.random() < 0.8 else vi - nv - 1
+                ni = rnd.randint(1, nn)
+                ni = ni if rnd.random() < 0.8 else ni - nn - 1
+                if nt and rnd.random() < 0.4:
+                    return "%d/%d/%d" % (vi, rnd.randint(1, nt), ni)
+                return "%d//%d" % (vi, ni)
+            lines.append("f " + rnd.choice([" ", "  ", "\t"]).join(corner() for _ in range(3)) + rnd.choice(["", " ", "\r"]))
+    return "\n".join(lines) + "\n"
+
+
+def test_obj_reader_fuzz_against_the_vendored_tinyobjloader(host, tmp_path):
+    """random OBJ/MTL files (corner forms with normals, relative indices, tabs, CR, groups, odd number spellings that
+    the parser reads its own way: "-.5", "1.", "1e", nine-digit decimals): the arrays MeshS takes from the parser are
+    bit for bit tinyobjloader's (live; needs oracle/_ref)"""
+    import random
+    from oracle import binding as ob
+    if not ob.ref_available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    rnd = random.Random(3)
+    for it in range(300):
+        kd = " ".join("%.6f" % rnd.uniform(0, 1) for _ in range(rnd.choice([1, 2, 3])))
+        (tmp_path / "m.mtl").write_text("newmtl a\nKd %s\nKe 1 1 1\nnewmtl b\nKd 0.5 0.5 0.5\nKs 0.1 0 0\nnewmtl c\nKe .5 0.25\n" % kd)
+        text = _random_obj(rnd)
+        (tmp_path / "x.obj").write_text(text)
+        want = ob.ref_obj_load(str(tmp_path / "x.obj"), str(tmp_path) + "/")
+        got = load(host, str(tmp_path / "x.obj"), str(tmp_path) + "/")
+        assert got["warnings"] == "", (got["warnings"], text)
+        for k in ("vertices", "normals", "tri_v", "tri_n", "mat"):
+            assert np.array_equal(want[k].view(np.uint32) if want[k].dtype == np.float32 else want[k],
+                                  got[k].view(np.uint32) if got[k].dtype == np.float32 else got[k]), (k, want[k].tolist(), got[k].tolist(), text)
+        assert np.array_equal(want["Kd"], got["rgb"]), (kd, want["Kd"].tolist(), got["rgb"].tolist())
