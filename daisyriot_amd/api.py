@@ -30,6 +30,10 @@ EXPORTS = [
     "dr_display_patch_colors", "dr_display_vertex_colors",
     "dr_formfactors_assemble_split", "dr_vis_exchange_bytes", "dr_vis_exchange_export", "dr_vis_exchange_import",
     "dr_formfactors_assemble_finish", "dr_vis_exchange_tracer", "dr_solver_skip_zero_blocks",
+    "dr_vis_exchange_fits", "dr_residual_chunk_floats", "dr_solver_set_check_interval", "dr_comm_info",
+    "dr_group_create", "dr_group_destroy", "dr_group_info", "dr_group_context", "dr_group_set_mesh",
+    "dr_group_assemble", "dr_group_solver_init", "dr_group_solver_step", "dr_group_solver_converge",
+    "dr_group_solver_reset", "dr_group_solver_read", "dr_group_synchronize",
 ]
 
 
@@ -87,22 +91,39 @@ def load_library(path=None):
     L.dr_debug_read_array.argtypes = [vp, i, vp, C.c_size_t]
     L.dr_comm_manual.argtypes = [vp]
     L.dr_exchange_export.argtypes = [vp, vp]
-    L.dr_exchange_import.argtypes = [vp, i, vp]
+    L.dr_exchange_import.argtypes = [vp, i, vp, C.c_size_t]
     L.dr_shard_rows.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.dr_residual_offset.argtypes = [i, i, i, i]
     L.dr_formfactors_assemble_split.argtypes = [vp, vp, i, C.c_float, i, i]
     L.dr_vis_exchange_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
-    L.dr_vis_exchange_export.argtypes = [vp, vp]
-    L.dr_vis_exchange_import.argtypes = [vp, i, vp]
+    L.dr_vis_exchange_export.argtypes = [vp, i, vp, C.c_size_t]
+    L.dr_vis_exchange_import.argtypes = [vp, i, vp, C.c_size_t]
+    L.dr_vis_exchange_fits.argtypes = [i, i, i, C.c_size_t]
+    L.dr_residual_chunk_floats.argtypes = [i, i]
+    L.dr_solver_set_check_interval.argtypes = [vp, i]
+    L.dr_comm_info.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+    L.dr_group_create.argtypes = [vp, i, C.POINTER(vp)]
+    L.dr_group_destroy.argtypes = [vp]
+    L.dr_group_info.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+    L.dr_group_context.argtypes = [vp, i, C.POINTER(vp)]
+    L.dr_group_set_mesh.argtypes = [vp, vp, i, vp, i, vp, vp, i]
+    L.dr_group_assemble.argtypes = [vp, vp, i, C.c_float, i, i]
+    L.dr_group_solver_init.argtypes = [vp, i, vp, vp, i, vp]
+    L.dr_group_solver_step.argtypes = [vp, i, C.POINTER(C.c_float)]
+    L.dr_group_solver_converge.argtypes = [vp, C.c_float, i, i, C.POINTER(i)]
+    L.dr_group_solver_reset.argtypes = [vp]
+    L.dr_group_solver_read.argtypes = [vp, vp, vp]
+    L.dr_group_synchronize.argtypes = [vp]
     L.dr_formfactors_assemble_finish.argtypes = [vp]
     L.dr_vis_exchange_tracer.argtypes = [i, i, i, i]
     L.dr_solver_skip_zero_blocks.argtypes = [vp, i]
     L.dr_display_patch_colors.argtypes = [vp, i, vp, vp]
     L.dr_display_vertex_colors.argtypes = [vp, vp, vp, vp, i, vp]
     for name in EXPORTS:
-        if name not in ("dr_last_error", "dr_residual_offset"):
+        if name not in ("dr_last_error", "dr_residual_offset", "dr_residual_chunk_floats"):
             getattr(L, name).restype = i
     L.dr_residual_offset.restype = C.c_size_t
+    L.dr_residual_chunk_floats.restype = C.c_size_t
     _lib = L
     return L
 
@@ -137,6 +158,17 @@ def residual_offset(i, s, S, rows_per_rank):
     return int(load_library().dr_residual_offset(int(i), int(s), int(S), int(rows_per_rank)))
 
 
+def residual_chunk_floats(S, rows_per_rank):
+    """floats of one rank's chunk of a gathered residual buffer: S*rows_per_rank values + the chunk's per-bin sums"""
+    return int(load_library().dr_residual_chunk_floats(int(S), int(rows_per_rank)))
+
+
+def vis_exchange_fits(N, world, keep_visibility, device_bytes):
+    """does a world-way assembly take the ray-count exchange path on cards of device_bytes?  (no rank argument: every
+    rank must decide alike) -- pure host arithmetic of the library"""
+    return bool(load_library().dr_vis_exchange_fits(int(N), int(world), int(bool(keep_visibility)), int(device_bytes)))
+
+
 def comm_unique_id():
     L = load_library()
     buf = np.zeros(128, np.uint8)
@@ -150,13 +182,17 @@ class Context:
     """One GPU's worth of the hot path.  Mirrors the call order of the reference:
     MeshS -> OptixPrimeFunctionality(mesh) -> Lightning (initMat, reset, passes)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
         self.L = load_library()
+        self.N = 0
+        self.S = 0
+        self._owned = _borrowed is None
+        if _borrowed is not None:        # a context that belongs to a Group
+            self.h = _borrowed
+            return
         h = C.c_void_p()
         self._chk(self.L.dr_context_create(int(device), C.byref(h)), "dr_context_create")
         self.h = h
-        self.N = 0
-        self.S = 0
 
     def _chk(self, rc, what):
         if rc != 0:
@@ -164,7 +200,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.dr_context_destroy(self.h)
+            if self._owned:
+                self.L.dr_context_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -196,18 +233,24 @@ class Context:
         assert id128.size == 128
         self._chk(self.L.dr_comm_init(self.h, _p(id128), int(rank), int(world)), "dr_comm_init")
 
+    def comm_info(self):
+        """(rank, world) the context's RCCL communicator itself reports; (-1, 0) without one"""
+        a, b = C.c_int(), C.c_int()
+        self._chk(self.L.dr_comm_info(self.h, C.byref(a), C.byref(b)), "dr_comm_info")
+        return a.value, b.value
+
     def comm_manual(self):
         self._chk(self.L.dr_comm_manual(self.h), "dr_comm_manual")
 
     def exchange_export(self):
         _, _, rpr = self.shard()
-        out = np.empty(self.S * rpr, np.float32)
+        out = np.empty(residual_chunk_floats(self.S, rpr), np.float32)
         self._chk(self.L.dr_exchange_export(self.h, _p(out)), "dr_exchange_export")
         return out
 
     def exchange_import(self, src_rank, chunk):
         chunk = _f32(chunk)
-        self._chk(self.L.dr_exchange_import(self.h, int(src_rank), _p(chunk)), "dr_exchange_import")
+        self._chk(self.L.dr_exchange_import(self.h, int(src_rank), _p(chunk), chunk.size), "dr_exchange_import")
 
     # -- scene
     def set_mesh(self, vertices, normals, tri_v, tri_n):
@@ -231,16 +274,17 @@ class Context:
         self._chk(self.L.dr_formfactors_assemble_split(self.h, _p(uv), uv.shape[0], C.c_float(eps), int(rule),
                                                        int(bool(keep_visibility))), "dr_formfactors_assemble_split")
 
-    def vis_exchange_export(self):
+    def vis_exchange_export(self, dst_rank):
+        """the block of ray-count slots this rank traced for dst_rank"""
         n = C.c_size_t()
         self._chk(self.L.dr_vis_exchange_bytes(self.h, C.byref(n)), "dr_vis_exchange_bytes")
         out = np.empty(n.value, np.uint8)
-        self._chk(self.L.dr_vis_exchange_export(self.h, _p(out)), "dr_vis_exchange_export")
+        self._chk(self.L.dr_vis_exchange_export(self.h, int(dst_rank), _p(out), out.size), "dr_vis_exchange_export")
         return out
 
-    def vis_exchange_import(self, src_rank, chunk):
-        chunk = np.ascontiguousarray(chunk, dtype=np.uint8)
-        self._chk(self.L.dr_vis_exchange_import(self.h, int(src_rank), _p(chunk)), "dr_vis_exchange_import")
+    def vis_exchange_import(self, src_rank, block):
+        block = np.ascontiguousarray(block, dtype=np.uint8)
+        self._chk(self.L.dr_vis_exchange_import(self.h, int(src_rank), _p(block), block.size), "dr_vis_exchange_import")
 
     def assemble_finish(self):
         self._chk(self.L.dr_formfactors_assemble_finish(self.h), "dr_formfactors_assemble_finish")
@@ -289,6 +333,10 @@ class Context:
         self._chk(self.L.dr_solver_converge(self.h, C.c_float(threshold), int(bool(per_bin)), int(max_iters),
                                             C.byref(it)), "dr_solver_converge")
         return it.value
+
+    def set_check_interval(self, passes):
+        """converge() looks at the device's convergence flag once per this many queued passes (default 8)"""
+        self._chk(self.L.dr_solver_set_check_interval(self.h, int(passes)), "dr_solver_set_check_interval")
 
     def reset(self):
         self._chk(self.L.dr_solver_reset(self.h), "dr_solver_reset")
@@ -360,3 +408,102 @@ class Context:
 
     def synchronize(self):
         self._chk(self.L.dr_synchronize(self.h), "dr_synchronize")
+
+
+class Group:
+    """One process, several GPUs (dr_group): rank r on devices[r], rows of F sharded over them, every call runs on all
+    devices at once.  The same device several times rehearses the group on one GPU (peer copies instead of RCCL)."""
+
+    def __init__(self, devices):
+        self.L = load_library()
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        self._chk(self.L.dr_group_create(_p(devs), devs.size, C.byref(h)), "dr_group_create")
+        self.h = h
+        self.n = int(devs.size)
+        self.N = 0
+        self.S = 0
+        self.ranks = []
+        for r in range(self.n):
+            ch = C.c_void_p()
+            self._chk(self.L.dr_group_context(self.h, r, C.byref(ch)), "dr_group_context")
+            self.ranks.append(Context(_borrowed=ch))
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise DaisyRiotError("%s failed (%d): %s" % (what, rc, self.L.dr_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            for c in self.ranks:
+                c.close()
+            self.L.dr_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def uses_rccl(self):
+        n, u = C.c_int(), C.c_int()
+        self._chk(self.L.dr_group_info(self.h, C.byref(n), C.byref(u)), "dr_group_info")
+        return bool(u.value)
+
+    def set_mesh(self, vertices, normals, tri_v, tri_n):
+        v, n = _f32(vertices).reshape(-1, 3), _f32(normals).reshape(-1, 3)
+        tv, tn = _i32(tri_v).reshape(-1, 3), _i32(tri_n).reshape(-1, 3)
+        self._chk(self.L.dr_group_set_mesh(self.h, _p(v), v.shape[0], _p(n), n.shape[0], _p(tv), _p(tn), tv.shape[0]),
+                  "dr_group_set_mesh")
+        self.N = tv.shape[0]
+        for c in self.ranks:
+            c.N = self.N
+
+    def assemble(self, uv, eps=ORIGIN_EPS, rule=RULE_INTEGRAND, keep_visibility=False):
+        uv = _f32(uv).reshape(-1, 2)
+        self._chk(self.L.dr_group_assemble(self.h, _p(uv), uv.shape[0], C.c_float(eps), int(rule), int(bool(keep_visibility))),
+                  "dr_group_assemble")
+
+    def solver_init(self, E, M, mat_of_patch):
+        E, M, mat = _f32(E), _f32(M), _i32(mat_of_patch)
+        if E.ndim == 1:
+            E = E.reshape(-1, 1)
+        S = E.shape[1]
+        if M.ndim == 1:
+            M = M.reshape(-1, 1, 1)
+        if E.shape[0] != self.N or mat.shape[0] != self.N or M.shape[1:] != (S, S):
+            raise DaisyRiotError("solver input shapes do not match N=%d S=%d" % (self.N, S))
+        self._chk(self.L.dr_group_solver_init(self.h, S, _p(E), _p(M), M.shape[0], _p(mat)), "dr_group_solver_init")
+        self.S = S
+        for c in self.ranks:
+            c.S = S
+
+    def step(self, n_passes=1, want_sum=False):
+        out = C.c_float()
+        self._chk(self.L.dr_group_solver_step(self.h, int(n_passes), C.byref(out) if want_sum else None), "dr_group_solver_step")
+        return out.value if want_sum else None
+
+    def converge(self, threshold, per_bin=False, max_iters=10000):
+        it = C.c_int()
+        self._chk(self.L.dr_group_solver_converge(self.h, C.c_float(threshold), int(bool(per_bin)), int(max_iters), C.byref(it)),
+                  "dr_group_solver_converge")
+        return it.value
+
+    def reset(self):
+        self._chk(self.L.dr_group_solver_reset(self.h), "dr_group_solver_reset")
+
+    def read(self):
+        b = np.zeros((self.N, self.S), np.float32)
+        r = np.zeros((self.N, self.S), np.float32)
+        self._chk(self.L.dr_group_solver_read(self.h, _p(b), _p(r)), "dr_group_solver_read")
+        return b, r
+
+    def synchronize(self):
+        self._chk(self.L.dr_group_synchronize(self.h), "dr_group_synchronize")

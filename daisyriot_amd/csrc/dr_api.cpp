@@ -61,6 +61,7 @@ struct dr_context {
     TriRec *d_tri = nullptr, *d_tri_sorted = nullptr;
     BvhNode* d_bvh = nullptr;
     int n_nodes = 0;
+    float scene_span = 0;     // max |coordinate| + diagonal of the scene (scale of the shaft culling's tolerances)
     // shard
     int rpr = 0, row0 = 0, nrows = 0;
     size_t ldF = 0;
@@ -69,9 +70,14 @@ struct dr_context {
     bool have_F = false;
     unsigned char* d_vis = nullptr;
     float* d_uv = nullptr;
-    // ray-count exchange of a multi-rank assembly (TileParams::vex): world * tiles_per_rank * nT slots of 64 x 64 bytes
-    unsigned char* d_vex = nullptr;
-    size_t vex_bytes = 0;
+    int uv_K = 0;                     // samples in d_uv
+    // ray-count exchange of a multi-rank assembly (TileParams::vsend / vrecv): per destination / source rank one block of
+    // tiles_per_rank^2 slots of 64 x 64 bytes
+    unsigned char *d_vsend = nullptr, *d_vrecv = nullptr;
+    size_t vx_block = 0;              // bytes of one block
+    int* d_agree = nullptr;           // world ints: the ranks' go / no-go before a collective (comm_agree)
+    EventPair* asm_ev = nullptr;      // around the tile kernel of an assembly in flight
+    unsigned long long h_cnt[16] = { 0 };
     bool split_pending = false;       // dr_formfactors_assemble_split done, ..._finish still to come
     int split_K = 0, split_rule = 0;
     float split_eps = 0;
@@ -80,8 +86,12 @@ struct dr_context {
     int S = 0, n_mat = 0;
     float *d_M = nullptr, *d_E = nullptr, *d_B = nullptr, *d_R[2] = { nullptr, nullptr };
     int* d_mat = nullptr;
-    double* d_sums = nullptr;
     float* d_Gpart = nullptr;
+    size_t cstride = 0;               // floats per rank chunk of the residual buffers: S*rpr + RTAIL (the chunk's per-bin sums)
+    unsigned* d_tickets = nullptr;    // in-launch reductions of the pass (SweepParams::tickets)
+    double* d_blk_sums = nullptr;
+    int* d_ctl = nullptr;             // [0] passes done, [1] a pass found the residual converged (SweepParams::ctl)
+    int check_every = 8;              // dr_solver_converge looks at d_ctl once per this many queued passes
     // optional zero-block skipping of the light pass (dr_solver_skip_zero_blocks)
     bool skip_zero = false, mask_valid = false;
     unsigned* d_mask = nullptr;
@@ -110,14 +120,16 @@ namespace {
 void free_F(dr_context* c) {
     hipFree(c->d_F); c->d_F = nullptr; c->F_floats = 0; c->have_F = false;
     hipFree(c->d_vis); c->d_vis = nullptr;
-    hipFree(c->d_vex); c->d_vex = nullptr; c->vex_bytes = 0; c->split_pending = false;
+    hipFree(c->d_vsend); hipFree(c->d_vrecv); c->d_vsend = c->d_vrecv = nullptr; c->vx_block = 0; c->split_pending = false;
     hipFree(c->d_mask); c->d_mask = nullptr; c->mask_valid = false; c->mask_words = 0;
 }
 void free_solver(dr_context* c) {
     hipFree(c->d_M); hipFree(c->d_E); hipFree(c->d_B); hipFree(c->d_R[0]); hipFree(c->d_R[1]);
-    hipFree(c->d_mat); hipFree(c->d_sums); hipFree(c->d_Gpart); c->d_Gpart = nullptr; hipFree(c->d_stage); c->d_stage = nullptr;
+    hipFree(c->d_mat); hipFree(c->d_Gpart); c->d_Gpart = nullptr; hipFree(c->d_stage); c->d_stage = nullptr;
+    hipFree(c->d_tickets); hipFree(c->d_blk_sums); hipFree(c->d_ctl);
+    c->d_tickets = nullptr; c->d_blk_sums = nullptr; c->d_ctl = nullptr;
     hipFree(c->d_rgb); c->d_rgb = nullptr; c->have_rgb = false;
-    c->d_M = c->d_E = c->d_B = c->d_R[0] = c->d_R[1] = nullptr; c->d_mat = nullptr; c->d_sums = nullptr;
+    c->d_M = c->d_E = c->d_B = c->d_R[0] = c->d_R[1] = nullptr; c->d_mat = nullptr;
     c->have_solver = false;
 }
 void free_scene(dr_context* c) {
@@ -188,12 +200,18 @@ int build_tile_mask(dr_context* c) {
     return DR_OK;
 }
 
-int sweep_once(dr_context* c) {
+// conv_mode / thr: SweepParams::conv_mode (0 = an unconditional pass)
+int sweep_once(dr_context* c, int conv_mode = 0, float thr = 0.0f) {
+    HIPCHK(hipSetDevice(c->device));
+    if (c->comm.comm && (c->comm.rank != c->rank || c->comm.world != c->world))
+        return fail(DR_ERR_STATE, "RCCL communicator is rank %d of %d, the shard is %d of %d", c->comm.rank, c->comm.world, c->rank, c->world);
     SweepParams p;
     p.N = c->N; p.S = c->S; p.rpr = c->rpr; p.world = c->world; p.row0 = c->row0; p.nrows = c->nrows;
     p.ldF = c->ldF; p.F = c->d_F; p.Rin = c->d_R[c->cur]; p.Rout = c->d_R[c->cur ^ 1]; p.rank = c->rank;
+    p.cstride = c->cstride;
     p.B = c->d_B; p.M = c->d_M; p.mat = c->d_mat; p.n_mat = c->n_mat;
     p.skew = 0; p.ksplit = c->ksplit; p.Gpart = c->d_Gpart;
+    p.tickets = c->d_tickets; p.blk_sums = c->d_blk_sums; p.ctl = c->d_ctl; p.conv_mode = conv_mode; p.conv_thr = thr;
     p.tile_mask = nullptr; p.mask_words = 0;
     if (c->skip_zero) {
         if (!c->mask_valid) { int rc = build_tile_mask(c); if (rc) return rc; }
@@ -219,17 +237,24 @@ int sweep_once(dr_context* c) {
     HIPCHK(launch_sweep(c->stream, p));
     if (c->profile) HIPCHK(hipEventRecord(e1, c->stream));
     if (c->comm.comm) {
-        std::string err = comm_allgather_inplace(c->comm, c->d_R[c->cur ^ 1], (size_t)c->S * c->rpr, c->stream);
+        std::string err = comm_allgather_inplace(c->comm, c->d_R[c->cur ^ 1], c->cstride, c->stream);
         if (!err.empty()) return fail(DR_ERR_COMM, "%s", err.c_str());
     }
     c->cur ^= 1;
     return DR_OK;
 }
 
+// per-bin sums of the current residual: the chunks' tails (kept by the passes themselves), added up chunk by chunk
 int read_sums(dr_context* c, double* sums) {
-    HIPCHK(launch_colsums(c->stream, c->d_R[c->cur], c->world, c->S, c->rpr, c->d_sums));
-    HIPCHK(hipMemcpyAsync(sums, c->d_sums, sizeof(double) * c->S, hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> tails((size_t)c->world * MAX_BINS);
+    HIPCHK(hipMemcpy2DAsync(tails.data(), sizeof(double) * MAX_BINS, c->d_R[c->cur] + (size_t)c->S * c->rpr, sizeof(float) * c->cstride,
+                            sizeof(double) * MAX_BINS, (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    for (int s = 0; s < c->S; s++) {
+        double t = 0.0;
+        for (int r = 0; r < c->world; r++) t += tails[(size_t)r * MAX_BINS + s];
+        sums[s] = t;
+    }
     return DR_OK;
 }
 
@@ -262,7 +287,8 @@ int dr_context_destroy(dr_context* c) {
     hipStreamSynchronize(c->stream);
     comm_destroy(c->comm);
     free_solver(c); free_F(c); free_scene(c);
-    hipFree(c->d_uv); hipFree(c->d_counter);
+    hipFree(c->d_uv); hipFree(c->d_counter); hipFree(c->d_agree);
+    delete c->asm_ev;
     for (auto& p : c->ev_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -279,7 +305,9 @@ int dr_set_stream(dr_context* c, void* hip_stream) {
 int dr_set_shard(dr_context* c, int rank, int world) {
     CTX(c);
     if (world < 1 || rank < 0 || rank >= world) return fail(DR_ERR_INVALID, "bad shard %d/%d", rank, world);
-    if (rank != c->rank || world != c->world) { free_F(c); free_solver(c); }
+    if ((rank != c->rank || world != c->world) && c->comm.comm)
+        return fail(DR_ERR_STATE, "the RCCL communicator of this context is rank %d of %d: the shard cannot change under it", c->comm.rank, c->comm.world);
+    if (rank != c->rank || world != c->world) { free_F(c); free_solver(c); hipFree(c->d_agree); c->d_agree = nullptr; }
     c->rank = rank; c->world = world;
     recompute_shard(c);
     return DR_OK;
@@ -302,9 +330,11 @@ int dr_vis_exchange_tracer(int N, int world, int patch_a, int patch_b) {
 }
 
 size_t dr_residual_offset(int i, int s, int S, int rpr) {
-    // chunk-major (one chunk per rank), bin-major inside a chunk: see sweep_kernels.hip
-    return ((size_t)(i / rpr) * S + s) * rpr + (size_t)(i % rpr);
+    // chunk-major (one chunk per rank), bin-major inside a chunk, each chunk followed by its per-bin sums: see sweep_kernels.hip
+    return (size_t)(i / rpr) * dr_residual_chunk_floats(S, rpr) + (size_t)s * rpr + (size_t)(i % rpr);
 }
+
+size_t dr_residual_chunk_floats(int S, int rpr) { return (size_t)S * rpr + RTAIL; }
 
 int dr_get_shard(dr_context* c, int* row0, int* nrows, int* rpr) {
     CTX(c);
@@ -367,46 +397,63 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     HIPCHK(hipStreamSynchronize(c->stream));
     c->last_bvh_ms = ev.ms();
     c->N = N; c->V = V; c->Nn = Nn;
+    c->scene_span = maxabs + std::sqrt(diag2);
     recompute_shard(c);
     return DR_OK;
 }
 
+// ---- assembly -------------------------------------------------------------------------------------------
 // vx_mode 0: self-sufficient (every pair that touches this rank's rows is traced here); 1 / 2: the two launches of an
-// assembly with ray-count exchange (TileParams); 2 reuses what 1 set up
-static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int rule, int keep_vis, int trace, int vx_mode = 0) {
+// assembly with ray-count exchange (TileParams); 2 reuses what 1 set up.  Three steps so that a group of contexts in
+// one process can run them on all its devices at once: prepare (allocations, uploads), launch (asynchronous),
+// complete (wait, bookkeeping).
+static int assemble_prepare(dr_context* c, const float* uv, int K, float eps, int rule, int keep_vis, int trace, int vx_mode) {
     CTX(c);
     if (c->N <= 0) return fail(DR_ERR_STATE, "dr_scene_set_mesh has not been called");
     if (trace && vx_mode != 2 && (!uv || K < 1 || K > 254)) return fail(DR_ERR_INVALID, "need 1 <= K <= 254 samples (K=%d)", K);
     if (rule != DR_RULE_INTEGRAND && rule != DR_RULE_RECIPROCITY) return fail(DR_ERR_INVALID, "unknown rule %d", rule);
-    const int nT = (c->N + TILE - 1) / TILE, tiles_per_rank = c->rpr / TILE;
-    if (vx_mode != 2) {
-        int rc = ensure_F(c);
-        if (rc) return rc;
-        c->have_F = false;
-        c->mask_valid = false;
-        c->split_pending = false;
-        if (c->ldF != (size_t)c->N) HIPCHK(hipMemsetAsync(c->d_F, 0, c->F_floats * sizeof(float), c->stream));
-        hipFree(c->d_vis); c->d_vis = nullptr;
-        if (keep_vis && c->nrows > 0) HIPCHK(hipMalloc(&c->d_vis, (size_t)c->nrows * c->N));
-        if (trace) {
-            hipFree(c->d_uv); c->d_uv = nullptr;
-            HIPCHK(hipMalloc(&c->d_uv, sizeof(float) * 2 * (size_t)K));
-            HIPCHK(hipMemcpyAsync(c->d_uv, uv, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, c->stream));
-        }
-        HIPCHK(hipMemsetAsync(c->d_counter, 0, 16 * sizeof(unsigned long long), c->stream));
-        if (vx_mode == 1) {
-            const size_t need = (size_t)c->world * tiles_per_rank * nT * (TILE * TILE);
-            if (c->vex_bytes != need) {
-                hipFree(c->d_vex); c->d_vex = nullptr; c->vex_bytes = 0;
-                hipError_t e = hipMalloc(&c->d_vex, need);
-                if (e != hipSuccess) { c->d_vex = nullptr; return fail(DR_ERR_NOMEM, "ray-count exchange buffer of %.2f GB: %s", need / 1e9, hipGetErrorString(e)); }
-                c->vex_bytes = need;
+    if (c->comm.comm && (c->comm.rank != c->rank || c->comm.world != c->world))
+        return fail(DR_ERR_STATE, "RCCL communicator is rank %d of %d, the shard is %d of %d", c->comm.rank, c->comm.world, c->rank, c->world);
+    const int tiles_per_rank = c->rpr / TILE;
+    if (vx_mode == 2) return DR_OK;
+    int rc = ensure_F(c);
+    if (rc) return rc;
+    c->have_F = false;
+    c->mask_valid = false;
+    c->split_pending = false;
+    if (c->ldF != (size_t)c->N) HIPCHK(hipMemsetAsync(c->d_F, 0, c->F_floats * sizeof(float), c->stream));
+    hipFree(c->d_vis); c->d_vis = nullptr;
+    if (keep_vis && c->nrows > 0) HIPCHK(hipMalloc(&c->d_vis, (size_t)c->nrows * c->N));
+    if (trace) {
+        hipFree(c->d_uv); c->d_uv = nullptr; c->uv_K = 0;
+        HIPCHK(hipMalloc(&c->d_uv, sizeof(float) * 2 * (size_t)K));
+        HIPCHK(hipMemcpyAsync(c->d_uv, uv, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, c->stream));
+        c->uv_K = K;
+    }
+    HIPCHK(hipMemsetAsync(c->d_counter, 0, 16 * sizeof(unsigned long long), c->stream));
+    if (vx_mode == 1) {
+        const size_t block = (size_t)tiles_per_rank * tiles_per_rank * (TILE * TILE);
+        if (c->vx_block != block || !c->d_vsend || !c->d_vrecv) {
+            hipFree(c->d_vsend); hipFree(c->d_vrecv); c->d_vsend = c->d_vrecv = nullptr; c->vx_block = 0;
+            hipError_t e = hipMalloc(&c->d_vsend, block * c->world);
+            if (e == hipSuccess) e = hipMalloc(&c->d_vrecv, block * c->world);
+            if (e != hipSuccess) {
+                hipFree(c->d_vsend); c->d_vsend = c->d_vrecv = nullptr;
+                return fail(DR_ERR_NOMEM, "ray-count exchange buffers of 2 x %.2f GB: %s", block * c->world / 1e9, hipGetErrorString(e));
             }
+            c->vx_block = block;
         }
     }
-    EventPair ev;
-    HIPCHK(ev.create());
-    HIPCHK(hipEventRecord(ev.a, c->stream));
+    c->split_K = K; c->split_rule = rule; c->split_eps = eps;
+    return DR_OK;
+}
+
+static int assemble_launch(dr_context* c, int K, float eps, int rule, int trace, int vx_mode) {
+    CTX(c);
+    delete c->asm_ev;
+    c->asm_ev = new EventPair();
+    HIPCHK(c->asm_ev->create());
+    HIPCHK(hipEventRecord(c->asm_ev->a, c->stream));
     if (c->nrows > 0) {
         TileParams p;
         p.N = c->N; p.K = trace ? K : 1; p.rule = rule; p.trace = trace;
@@ -414,93 +461,151 @@ static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int r
         p.row0 = c->row0; p.nrows = c->nrows; p.n_nodes = c->n_nodes; p.eps = eps; p.ldF = c->ldF;
         p.F = c->d_F; p.vis = c->d_vis; p.patch = c->d_patch; p.tri = c->d_tri; p.tri_sorted = c->d_tri_sorted; p.bvh = c->d_bvh;
         p.uv = c->d_uv; p.pairs_traced = c->d_counter;
-        p.vx_mode = vx_mode; p.vx_rank = c->rank; p.vx_tiles_per_rank = tiles_per_rank; p.vex = c->d_vex;
+        p.vx_mode = vx_mode; p.vx_rank = c->rank; p.vx_tiles_per_rank = c->rpr / TILE; p.vsend = c->d_vsend; p.vrecv = c->d_vrecv;
+        // tile-pair shaft culling (geom_kernels.hip), off unless DR_SHAFT=1: exact, but measured slower than walks from
+        // the root (profiles/r02/assembly_notes.md); DR_SHAFT_MIN = nodes below which a subtree is listed whole
+        { const char* e = getenv("DR_SHAFT"); p.shaft = e ? atoi(e) : 0; }
+        { const char* e = getenv("DR_SHAFT_MIN"); p.shaft_min_bytes = (e ? atoi(e) : 128) * (int)sizeof(BvhNode); }
+        { const char* e = getenv("DR_SHAFT_SHRINK"); p.shaft_near_shrink = e ? (float)atof(e) : 0.25f; }
+        p.shaft_pad_ray = 1e-6f * c->scene_span; p.shaft_pad_node = 5e-6f * c->scene_span; p.shaft_tol = c->scene_span;
         p.stats = getenv("DR_TILE_STATS") ? 1 : 0;
         p.dbg_lo = p.dbg_hi = -1;
         if (const char* dp = getenv("DR_DEBUG_PAIR")) { p.stats = 1; p.dbg_ray = 0; sscanf(dp, "%d,%d,%d", &p.dbg_lo, &p.dbg_hi, &p.dbg_ray); }
         HIPCHK(launch_ff_tiles(c->stream, p));
     }
-    HIPCHK(hipEventRecord(ev.b, c->stream));
-    unsigned long long cnt[16] = { 0 };
-    HIPCHK(hipMemcpyAsync(cnt, c->d_counter, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(c->asm_ev->b, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_cnt, c->d_counter, sizeof c->h_cnt, hipMemcpyDeviceToHost, c->stream));
+    return DR_OK;
+}
+
+static int assemble_complete(dr_context* c, int vx_mode) {
+    CTX(c);
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->last_assemble_ms = (vx_mode == 2 ? c->last_assemble_ms : 0.0) + ev.ms();
+    const unsigned long long* cnt = c->h_cnt;
+    c->last_assemble_ms = (vx_mode == 2 ? c->last_assemble_ms : 0.0) + (c->asm_ev ? c->asm_ev->ms() : 0.0);
+    delete c->asm_ev; c->asm_ev = nullptr;
     c->pairs_traced = cnt[0]; c->stat_visits = cnt[1]; c->stat_leaves = cnt[2];
     if (getenv("DR_DEBUG_PAIR"))
         fprintf(stderr, "[daisyriot] debug pair: live mask after target test %016llx, final %016llx; blocker of the debug ray: patch %lld "
                         "t %08llx tmax %08llx node %llu\n", cnt[1], cnt[3], (long long)cnt[4], cnt[5], cnt[6], cnt[7]);
     else if (getenv("DR_TILE_STATS"))
-        fprintf(stderr, "[daisyriot] pairs %llu, node visits %llu (%.1f/pair), leaf tests %llu (%.1f/pair)\n", cnt[0], cnt[1],
-                cnt[0] ? (double)cnt[1] / cnt[0] : 0.0, cnt[2], cnt[0] ? (double)cnt[2] / cnt[0] : 0.0);
+        fprintf(stderr, "[daisyriot] pairs %llu, node visits %llu (%.1f/pair), leaf tests %llu (%.1f/pair); shaft lists: %llu tile pairs, "
+                        "%.1f ranges and %.1f nodes looked at per list, %llu pairs walked from the root\n", cnt[0], cnt[1],
+                cnt[0] ? (double)cnt[1] / cnt[0] : 0.0, cnt[2], cnt[0] ? (double)cnt[2] / cnt[0] : 0.0, cnt[11],
+                cnt[11] ? (double)cnt[8] / cnt[11] : 0.0, cnt[11] ? (double)cnt[9] / cnt[11] : 0.0, cnt[10]);
     if (vx_mode == 1) {
-        c->split_pending = true; c->split_K = K; c->split_rule = rule; c->split_eps = eps;
+        c->split_pending = true;
     } else {
         c->split_pending = false;
         c->have_F = true;
         c->mask_valid = false;
-        if (vx_mode == 2) { hipFree(c->d_vex); c->d_vex = nullptr; c->vex_bytes = 0; }      // N*N bytes: not kept
+        if (vx_mode == 2) {       // 2 N^2/world bytes: not kept
+            hipFree(c->d_vsend); hipFree(c->d_vrecv); c->d_vsend = c->d_vrecv = nullptr; c->vx_block = 0;
+        }
     }
+    return DR_OK;
+}
+
+static int assemble_impl(dr_context* c, const float* uv, int K, float eps, int rule, int keep_vis, int trace, int vx_mode = 0) {
+    int rc = assemble_prepare(c, uv, K, eps, rule, keep_vis, trace, vx_mode);
+    if (rc) return rc;
+    rc = assemble_launch(c, K, eps, rule, trace, vx_mode);
+    if (rc) return rc;
+    return assemble_complete(c, vx_mode);
+}
+
+// Device bytes one rank of a world-way assembly WITH ray-count exchange holds: the two slot buffers, its F shard, the
+// optional ray counts.  A function of rank-independent quantities only (rows per rank, not this rank's rows), so every
+// rank of a homogeneous node takes the same decision -- a rank that decided alone would strand its peers in the collective.
+static double vx_bytes_needed(int N, int world, int keep_vis) {
+    int row0, nrows, rpr;
+    shard_rows(N, 0, world, &row0, &nrows, &rpr);
+    const double T = rpr / TILE;
+    return 2.0 * world * T * T * (TILE * TILE) + 4.0 * rpr * ((double)world * rpr) + (keep_vis ? (double)rpr * N : 0.0);
+}
+
+int dr_vis_exchange_fits(int N, int world, int keep_visibility, size_t device_bytes) {
+    if (N < 1 || world < 1) return 0;
+    return vx_bytes_needed(N, world, keep_visibility) <= 0.85 * (double)device_bytes ? 1 : 0;
+}
+
+// every rank's go (1) / no-go (0) before a collective: all ranks return the minimum
+static int comm_agree(dr_context* c, int ok, int* all_ok) {
+    if (!c->d_agree) HIPCHK(hipMalloc(&c->d_agree, sizeof(int) * (size_t)std::max(c->world, 1)));
+    HIPCHK(hipMemcpyAsync(c->d_agree + c->rank, &ok, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));      // `ok` is a stack variable
+    std::string err = comm_allgather_i32_inplace(c->comm, c->d_agree, c->stream);
+    if (!err.empty()) return fail(DR_ERR_COMM, "%s", err.c_str());
+    std::vector<int> h((size_t)c->world);
+    HIPCHK(hipMemcpyAsync(h.data(), c->d_agree, sizeof(int) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *all_ok = 1;
+    for (int v : h) *all_ok = std::min(*all_ok, v);
     return DR_OK;
 }
 
 int dr_formfactors_assemble(dr_context* c, const float* uv, int K, float eps, int rule, int keep_vis) {
     if (!c) return fail(DR_ERR_INVALID, "null context");
     // several ranks joined by RCCL: every pair between two ranks' rows is traced by one of them only and its 64 x 64
-    // ray counts are exchanged (one all-gather of the slot buffers); otherwise the rank is self-sufficient
+    // ray counts travel to the other (one all-to-all of slot blocks); otherwise the rank is self-sufficient
     // (DR_VIS_EXCHANGE_REHEARSE: take this path with a single-rank communicator too -- a one-GPU rehearsal of the calls)
     bool exchange = (c->world > 1 || getenv("DR_VIS_EXCHANGE_REHEARSE")) && c->comm.comm && !getenv("DR_NO_VIS_EXCHANGE");
     if (exchange) {
-        // the slot buffer is N*N bytes on every rank; when it does not fit beside the F shard every rank traces for
-        // itself.  Decided from the card's TOTAL memory, so that all ranks of a homogeneous node decide alike.
+        // when the slot buffers do not fit beside the F shard every rank traces for itself.  Decided from rank-independent
+        // numbers and the card's TOTAL memory, so that all ranks of a homogeneous node decide alike.
         HIPCHK(hipSetDevice(c->device));
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, c->device));
-        const int nT = (c->N + TILE - 1) / TILE;
-        const double need = (double)c->world * (c->rpr / TILE) * nT * (TILE * TILE) + 4.0 * std::max(c->nrows, 1) * (double)c->ldF +
-                            (keep_vis ? (double)c->nrows * c->N : 0.0);
-        if (need > 0.85 * (double)prop.totalGlobalMem) exchange = false;
+        if (!dr_vis_exchange_fits(c->N, c->world, keep_vis, prop.totalGlobalMem)) exchange = false;
     }
-    if (exchange) {
-        int rc = assemble_impl(c, uv, K, eps, rule, keep_vis, 1, 1);
-        if (rc) return rc;
-        const size_t chunk = c->vex_bytes / (size_t)c->world;
-        std::string err = comm_allgather_bytes_inplace(c->comm, c->d_vex, chunk, c->stream);
-        if (!err.empty()) return fail(DR_ERR_COMM, "%s", err.c_str());
-        return assemble_impl(c, nullptr, c->split_K, c->split_eps, c->split_rule, 0, 1, 2);
-    }
-    return assemble_impl(c, uv, K, eps, rule, keep_vis, 1);
+    if (!exchange) return assemble_impl(c, uv, K, eps, rule, keep_vis, 1);
+    // allocations first, then the ranks agree that all of them can go on: an out-of-memory on one rank must not leave the
+    // others waiting in the collective
+    int rc = assemble_prepare(c, uv, K, eps, rule, keep_vis, 1, 1);
+    int all_ok = 0;
+    int rc2 = comm_agree(c, rc == DR_OK ? 1 : 0, &all_ok);
+    if (rc) return rc;
+    if (rc2) return rc2;
+    if (!all_ok) return fail(DR_ERR_COMM, "another rank could not set up the assembly; nothing was traced");
+    rc = assemble_launch(c, K, eps, rule, 1, 1);
+    if (rc) return rc;
+    rc = assemble_complete(c, 1);
+    if (rc) return rc;
+    std::string err = comm_alltoall_bytes(c->comm, c->d_vsend, c->d_vrecv, c->vx_block, c->stream);
+    if (!err.empty()) return fail(DR_ERR_COMM, "%s", err.c_str());
+    return assemble_impl(c, nullptr, c->split_K, c->split_eps, c->split_rule, 0, 1, 2);
 }
 
-/* the same in three steps for a host that moves the slot buffers itself (tests, MPI staging) */
+/* the same in three steps for a host that moves the slot blocks itself (tests, MPI staging) */
 int dr_formfactors_assemble_split(dr_context* c, const float* uv, int K, float eps, int rule, int keep_vis) {
     if (!c) return fail(DR_ERR_INVALID, "null context");
     return assemble_impl(c, uv, K, eps, rule, keep_vis, 1, 1);
 }
 
-int dr_vis_exchange_bytes(dr_context* c, size_t* chunk_bytes) {
+int dr_vis_exchange_bytes(dr_context* c, size_t* block_bytes) {
     CTX(c);
-    if (!chunk_bytes) return fail(DR_ERR_INVALID, "chunk_bytes is null");
+    if (!block_bytes) return fail(DR_ERR_INVALID, "block_bytes is null");
     if (!c->split_pending) return fail(DR_ERR_STATE, "dr_formfactors_assemble_split has not been called");
-    *chunk_bytes = c->vex_bytes / (size_t)c->world;
+    *block_bytes = c->vx_block;
     return DR_OK;
 }
 
-int dr_vis_exchange_export(dr_context* c, void* out) {
+int dr_vis_exchange_export(dr_context* c, int dst_rank, void* out, size_t bytes) {
     CTX(c);
-    if (!out) return fail(DR_ERR_INVALID, "out is null");
+    if (!out || dst_rank < 0 || dst_rank >= c->world) return fail(DR_ERR_INVALID, "bad destination rank %d", dst_rank);
     if (!c->split_pending) return fail(DR_ERR_STATE, "dr_formfactors_assemble_split has not been called");
-    const size_t chunk = c->vex_bytes / (size_t)c->world;
-    HIPCHK(hipMemcpyAsync(out, c->d_vex + (size_t)c->rank * chunk, chunk, hipMemcpyDeviceToHost, c->stream));
+    if (bytes != c->vx_block) return fail(DR_ERR_INVALID, "a slot block is %zu bytes (dr_vis_exchange_bytes), got %zu", c->vx_block, bytes);
+    HIPCHK(hipMemcpyAsync(out, c->d_vsend + (size_t)dst_rank * c->vx_block, c->vx_block, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return DR_OK;
 }
 
-int dr_vis_exchange_import(dr_context* c, int src_rank, const void* in) {
+int dr_vis_exchange_import(dr_context* c, int src_rank, const void* in, size_t bytes) {
     CTX(c);
     if (!in || src_rank < 0 || src_rank >= c->world) return fail(DR_ERR_INVALID, "bad source rank %d", src_rank);
     if (!c->split_pending) return fail(DR_ERR_STATE, "dr_formfactors_assemble_split has not been called");
-    const size_t chunk = c->vex_bytes / (size_t)c->world;
-    HIPCHK(hipMemcpyAsync(c->d_vex + (size_t)src_rank * chunk, in, chunk, hipMemcpyHostToDevice, c->stream));
+    if (bytes != c->vx_block) return fail(DR_ERR_INVALID, "a slot block is %zu bytes (dr_vis_exchange_bytes), got %zu", c->vx_block, bytes);
+    HIPCHK(hipMemcpyAsync(c->d_vrecv + (size_t)src_rank * c->vx_block, in, c->vx_block, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return DR_OK;
 }
@@ -578,23 +683,30 @@ int dr_solver_init(dr_context* c, int S, const float* E, const float* M, int n_m
     HIPCHK(hipStreamSynchronize(c->stream));
     free_solver(c);
     c->S = S; c->n_mat = n_mat;
-    const size_t full = (size_t)c->world * S * c->rpr;
+    c->cstride = (size_t)S * c->rpr + RTAIL;
+    const size_t full = (size_t)c->world * c->cstride;
     HIPCHK(hipMalloc(&c->d_M, sizeof(float) * (size_t)n_mat * S * S));
     HIPCHK(hipMalloc(&c->d_E, sizeof(float) * full));
     HIPCHK(hipMalloc(&c->d_R[0], sizeof(float) * full));
     HIPCHK(hipMalloc(&c->d_R[1], sizeof(float) * full));
     HIPCHK(hipMalloc(&c->d_B, sizeof(float) * (size_t)S * c->rpr));
     HIPCHK(hipMalloc(&c->d_mat, sizeof(int) * (size_t)c->rpr));
-    HIPCHK(hipMalloc(&c->d_sums, sizeof(double) * DR_MAX_BINS));
     c->ksplit = sweep_ksplit(c->nrows, S, (int)c->ldF);
     if (c->ksplit > 1) HIPCHK(hipMalloc(&c->d_Gpart, sizeof(float) * (size_t)c->ksplit * std::max(c->nrows, 1) * S));
+    const size_t row_blocks = (size_t)std::max(sweep_row_blocks(c->nrows, S), 1);
+    HIPCHK(hipMalloc(&c->d_tickets, sizeof(unsigned) * (1 + row_blocks)));
+    HIPCHK(hipMalloc(&c->d_blk_sums, sizeof(double) * row_blocks * S));
+    HIPCHK(hipMalloc(&c->d_ctl, sizeof(int) * 4));
+    HIPCHK(hipMemsetAsync(c->d_tickets, 0, sizeof(unsigned) * (1 + row_blocks), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_ctl, 0, sizeof(int) * 4, c->stream));
     HIPCHK(hipMalloc(&c->d_stage, sizeof(float) * std::max((size_t)c->N * S, (size_t)3 * DR_MAX_BINS)));
     float* tmp = c->d_stage;
     HIPCHK(hipMemcpyAsync(tmp, E, sizeof(float) * (size_t)c->N * S, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->d_E, 0, sizeof(float) * full, c->stream));
     HIPCHK(hipMemsetAsync(c->d_R[0], 0, sizeof(float) * full, c->stream));
     HIPCHK(hipMemsetAsync(c->d_R[1], 0, sizeof(float) * full, c->stream));
-    HIPCHK(launch_scatter_rows(c->stream, tmp, c->N, S, c->rpr, c->world, c->d_E));
+    HIPCHK(launch_scatter_rows(c->stream, tmp, c->N, S, c->rpr, c->cstride, c->d_E));
+    HIPCHK(launch_chunk_sums(c->stream, c->d_E, c->world, S, c->rpr, c->cstride));
     HIPCHK(hipMemcpyAsync(c->d_M, M, sizeof(float) * (size_t)n_mat * S * S, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->d_mat, 0, sizeof(int) * (size_t)c->rpr, c->stream));
     if (c->nrows > 0)
@@ -607,10 +719,10 @@ int dr_solver_init(dr_context* c, int S, const float* E, const float* M, int n_m
 int dr_solver_reset(dr_context* c) {
     CTX(c);
     if (!c->have_solver) return fail(DR_ERR_STATE, "dr_solver_init has not been called");
-    const size_t full = (size_t)c->world * c->S * c->rpr;
+    const size_t full = (size_t)c->world * c->cstride;
     c->cur = 0;
     HIPCHK(hipMemcpyAsync(c->d_R[0], c->d_E, sizeof(float) * full, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_B, c->d_E + (size_t)c->rank * c->S * c->rpr, sizeof(float) * (size_t)c->S * c->rpr,
+    HIPCHK(hipMemcpyAsync(c->d_B, c->d_E + (size_t)c->rank * c->cstride, sizeof(float) * (size_t)c->S * c->rpr,
                           hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return DR_OK;
@@ -654,20 +766,40 @@ int dr_solver_converge(dr_context* c, float threshold, int per_bin, int max_iter
     if (!c->have_solver) return fail(DR_ERR_STATE, "dr_solver_init has not been called");
     if (!c->have_F) return fail(DR_ERR_STATE, "form factors not assembled");
     if (max_iters < 0) return fail(DR_ERR_INVALID, "max_iters < 0");
-    int it = 0;
+    // The test "has the residual converged?" runs on the device, at the head of every pass, from the per-bin sums the
+    // previous pass left in the residual's tails (gathered with it); a pass that finds it converged does nothing.  The
+    // host queues passes in batches of check_every and looks at the counters once per batch -- every rank reads the same
+    // counters (they are functions of the gathered sums), so all ranks queue the same passes and collectives.
+    HIPCHK(hipMemsetAsync(c->d_ctl, 0, sizeof(int) * 4, c->stream));
+    const int cur0 = c->cur;
+    int queued = 0, ctl[2] = { 0, 0 };
+    const int mode = per_bin ? 2 : 1;
     for (;;) {
-        double sums[DR_MAX_BINS];
-        int rc = read_sums(c, sums);
-        if (rc) return rc;
-        bool go = false;
-        if (per_bin) { for (int s = 0; s < c->S; s++) go = go || (sums[s] > (double)threshold); }
-        else { double t = 0; for (int s = 0; s < c->S; s++) t += sums[s]; go = t > (double)threshold; }
-        if (!go || it >= max_iters) break;
-        rc = sweep_once(c);
-        if (rc) return rc;
-        it++;
+        const int batch = std::min(c->check_every, max_iters - queued);
+        for (int k = 0; k < batch; k++) {
+            int rc = sweep_once(c, mode, threshold);
+            if (rc) return rc;
+        }
+        queued += batch;
+        if (batch == 0) {
+            // cap reached (or max_iters = 0): nothing queued
+            break;
+        }
+        HIPCHK(hipMemcpyAsync(ctl, c->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (getenv("DR_DEBUG_CONV")) fprintf(stderr, "[daisyriot] converge: queued %d, passes done %d, converged flag %d\n", queued, ctl[0], ctl[1]);
+        if (ctl[1] != 0 || ctl[0] < queued || queued >= max_iters) break;
     }
-    if (iters_out) *iters_out = it;
+    // passes after the converged one did nothing: the current residual is the one the last REAL pass wrote
+    c->cur = cur0 ^ (ctl[0] & 1);
+    if (iters_out) *iters_out = ctl[0];
+    return DR_OK;
+}
+
+int dr_solver_set_check_interval(dr_context* c, int passes) {
+    CTX(c);
+    if (passes < 1) return fail(DR_ERR_INVALID, "check interval %d < 1", passes);
+    c->check_every = passes;
     return DR_OK;
 }
 
@@ -676,12 +808,12 @@ int dr_solver_read(dr_context* c, float* B, float* R) {
     if (!c->have_solver) return fail(DR_ERR_STATE, "dr_solver_init has not been called");
     float* tmp = c->d_stage;
     if (R) {
-        HIPCHK(launch_gather_rows(c->stream, c->d_R[c->cur], c->N, c->S, c->rpr, c->world, tmp));
+        HIPCHK(launch_gather_rows(c->stream, c->d_R[c->cur], c->N, c->S, c->rpr, c->cstride, tmp));
         HIPCHK(hipMemcpyAsync(R, tmp, sizeof(float) * (size_t)c->N * c->S, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     if (B && c->nrows > 0) {
-        HIPCHK(launch_gather_rows(c->stream, c->d_B, c->nrows, c->S, c->rpr, 1, tmp));
+        HIPCHK(launch_gather_rows(c->stream, c->d_B, c->nrows, c->S, c->rpr, (size_t)c->S * c->rpr, tmp));
         HIPCHK(hipMemcpyAsync(B + (size_t)c->row0 * c->S, tmp, sizeof(float) * (size_t)c->nrows * c->S, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
@@ -780,17 +912,18 @@ int dr_exchange_export(dr_context* c, float* out) {
     CTX(c);
     if (!c->have_solver) return fail(DR_ERR_STATE, "dr_solver_init has not been called");
     if (!out) return fail(DR_ERR_INVALID, "chunk_out is null");
-    const size_t n = (size_t)c->S * c->rpr;
+    const size_t n = c->cstride;
     HIPCHK(hipMemcpyAsync(out, c->d_R[c->cur] + (size_t)c->rank * n, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return DR_OK;
 }
 
-int dr_exchange_import(dr_context* c, int src_rank, const float* in) {
+int dr_exchange_import(dr_context* c, int src_rank, const float* in, size_t n_floats) {
     CTX(c);
     if (!c->have_solver) return fail(DR_ERR_STATE, "dr_solver_init has not been called");
     if (!in || src_rank < 0 || src_rank >= c->world) return fail(DR_ERR_INVALID, "bad source rank %d", src_rank);
-    const size_t n = (size_t)c->S * c->rpr;
+    const size_t n = c->cstride;
+    if (n_floats != n) return fail(DR_ERR_INVALID, "a residual chunk is %zu floats (dr_residual_chunk_floats), got %zu", n, n_floats);
     HIPCHK(hipMemcpyAsync(c->d_R[c->cur] + (size_t)src_rank * n, in, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return DR_OK;
@@ -803,7 +936,7 @@ int dr_debug_read_array(dr_context* c, int which, void* out, size_t bytes) {
     switch (which) {
         case 0: src = c->d_tri; have = sizeof(TriRec) * (size_t)c->N; break;
         case 1: src = c->d_tri_sorted; have = sizeof(TriRec) * ((size_t)c->N + LEAF_MAX); break;
-        case 3: src = c->d_uv; have = bytes; break;
+        case 3: src = c->d_uv; have = sizeof(float) * 2 * (size_t)c->uv_K; break;
         case 4: src = c->d_patch; have = sizeof(PatchRec) * (size_t)c->N; break;
         default: return fail(DR_ERR_INVALID, "unknown array %d", which);
     }
@@ -847,6 +980,254 @@ int dr_synchronize(dr_context* c) {
     CTX(c);
     HIPCHK(hipStreamSynchronize(c->stream));
     return DR_OK;
+}
+
+int dr_comm_info(dr_context* c, int* rccl_rank, int* rccl_world) {
+    CTX(c);
+    if (rccl_rank) *rccl_rank = c->comm.comm ? c->comm.rank : -1;
+    if (rccl_world) *rccl_world = c->comm.comm ? c->comm.world : 0;
+    return DR_OK;
+}
+
+/* ---- one process, several GPUs ------------------------------------------------------------------------- */
+struct dr_group {
+    std::vector<dr_context*> ctx;
+    std::vector<int> devices;
+    bool rccl = false;                  // residual / ray-count exchange through RCCL (distinct devices); else peer copies
+    std::vector<hipEvent_t> ev_done;    // per rank: its pass has written its chunk (peer-copy exchange)
+};
+
+#define GRP(g) do { if (!(g) || (g)->ctx.empty()) return fail(DR_ERR_INVALID, "null group"); } while (0)
+
+static int group_sync(dr_group* g) {
+    for (dr_context* c : g->ctx) { int rc = dr_synchronize(c); if (rc) return rc; }
+    return DR_OK;
+}
+
+int dr_group_destroy(dr_group* g) {
+    if (!g) return DR_OK;
+    for (dr_context* c : g->ctx) if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); }
+    for (size_t r = 0; r < g->ev_done.size(); r++) { hipSetDevice(g->devices[r]); hipEventDestroy(g->ev_done[r]); }
+    for (dr_context* c : g->ctx) dr_context_destroy(c);
+    delete g;
+    return DR_OK;
+}
+
+int dr_group_create(const int* device_ids, int n, dr_group** out) {
+    if (!out || !device_ids || n < 1) return fail(DR_ERR_INVALID, "need at least one device");
+    dr_group* g = new dr_group();
+    bool distinct = true;
+    for (int r = 0; r < n; r++) {
+        for (int q = 0; q < r; q++) distinct = distinct && device_ids[q] != device_ids[r];
+        dr_context* c = nullptr;
+        int rc = dr_context_create(device_ids[r], &c);
+        if (rc) { dr_group_destroy(g); return rc; }
+        g->ctx.push_back(c);
+        g->devices.push_back(device_ids[r]);
+        c->rank = r; c->world = n;
+    }
+    // Distinct devices: RCCL (ncclCommInitAll), as between processes.  The same device several times (a one-GPU
+    // rehearsal of the group) cannot be an RCCL communicator: peer copies then -- also selectable with DR_GROUP_EXCHANGE=p2p.
+    const char* ex = getenv("DR_GROUP_EXCHANGE");
+    g->rccl = n > 1 && distinct && !(ex && !strcmp(ex, "p2p"));
+    if (g->rccl) {
+        std::vector<Comm> cs;
+        std::string e = comm_init_all(cs, device_ids, n);
+        if (!e.empty()) { dr_group_destroy(g); return fail(DR_ERR_COMM, "%s", e.c_str()); }
+        for (int r = 0; r < n; r++) g->ctx[r]->comm = cs[r];
+    } else {
+        for (int r = 0; r < n; r++) {
+            g->ctx[r]->manual_exchange = true;
+            hipSetDevice(device_ids[r]);
+            hipEvent_t ev;
+            hipError_t he = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (he != hipSuccess) { dr_group_destroy(g); return fail(DR_ERR_DEVICE, "hipEventCreate: %s", hipGetErrorString(he)); }
+            g->ev_done.push_back(ev);
+            for (int q = 0; q < n; q++)        // direct xGMI copies where the devices allow it (an error here only means staged copies)
+                if (device_ids[q] != device_ids[r]) { (void)hipDeviceEnablePeerAccess(device_ids[q], 0); (void)hipGetLastError(); }
+        }
+    }
+    *out = g;
+    return DR_OK;
+}
+
+int dr_group_info(dr_group* g, int* n, int* uses_rccl) {
+    GRP(g);
+    if (n) *n = (int)g->ctx.size();
+    if (uses_rccl) *uses_rccl = g->rccl ? 1 : 0;
+    return DR_OK;
+}
+
+int dr_group_context(dr_group* g, int rank, dr_context** out) {
+    GRP(g);
+    if (!out || rank < 0 || rank >= (int)g->ctx.size()) return fail(DR_ERR_INVALID, "rank %d outside the group", rank);
+    *out = g->ctx[rank];
+    return DR_OK;
+}
+
+int dr_group_set_mesh(dr_group* g, const float* vertices, int V, const float* normals, int Nn, const int32_t* tv, const int32_t* tn, int N) {
+    GRP(g);
+    for (dr_context* c : g->ctx) { int rc = dr_scene_set_mesh(c, vertices, V, normals, Nn, tv, tn, N); if (rc) return rc; }
+    return DR_OK;
+}
+
+int dr_group_assemble(dr_group* g, const float* uv, int K, float eps, int rule, int keep_vis) {
+    GRP(g);
+    const int n = (int)g->ctx.size();
+    bool exchange = n > 1 && !getenv("DR_NO_VIS_EXCHANGE");
+    if (exchange) {
+        dr_context* c0 = g->ctx[0];
+        HIPCHK(hipSetDevice(c0->device));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, c0->device));
+        // several ranks on ONE card (rehearsal) share its memory
+        size_t per_rank = prop.totalGlobalMem;
+        if (!g->rccl) { int same = 0; for (int d : g->devices) same += d == g->devices[0]; per_rank /= (size_t)std::max(same, 1); }
+        if (!dr_vis_exchange_fits(c0->N, n, keep_vis, per_rank)) exchange = false;
+    }
+    const int mode1 = exchange ? 1 : 0;
+    for (dr_context* c : g->ctx) { int rc = assemble_prepare(c, uv, K, eps, rule, keep_vis, 1, mode1); if (rc) return rc; }
+    for (dr_context* c : g->ctx) { int rc = assemble_launch(c, K, eps, rule, 1, mode1); if (rc) return rc; }     // all devices at once
+    for (dr_context* c : g->ctx) { int rc = assemble_complete(c, mode1); if (rc) return rc; }
+    if (!exchange) return DR_OK;
+    if (g->rccl) {
+        std::string e = comm_group_start();
+        for (int r = 0; r < n && e.empty(); r++) {
+            dr_context* c = g->ctx[r];
+            HIPCHK(hipSetDevice(c->device));
+            e = comm_alltoall_bytes(c->comm, c->d_vsend, c->d_vrecv, c->vx_block, c->stream);
+        }
+        std::string e2 = comm_group_end();
+        if (e.empty()) e = e2;
+        if (!e.empty()) return fail(DR_ERR_COMM, "%s", e.c_str());
+    } else {
+        for (int d = 0; d < n; d++) {
+            dr_context* cd = g->ctx[d];
+            HIPCHK(hipSetDevice(cd->device));
+            for (int r = 0; r < n; r++) {
+                if (r == d) continue;
+                dr_context* cr = g->ctx[r];
+                HIPCHK(hipMemcpyPeerAsync(cd->d_vrecv + (size_t)r * cd->vx_block, cd->device, cr->d_vsend + (size_t)d * cr->vx_block, cr->device,
+                                          cd->vx_block, cd->stream));
+            }
+        }
+    }
+    for (dr_context* c : g->ctx) { int rc = assemble_prepare(c, nullptr, c->split_K, c->split_eps, c->split_rule, 0, 1, 2); if (rc) return rc; }
+    for (dr_context* c : g->ctx) { int rc = assemble_launch(c, c->split_K, c->split_eps, c->split_rule, 1, 2); if (rc) return rc; }
+    for (dr_context* c : g->ctx) { int rc = assemble_complete(c, 2); if (rc) return rc; }
+    return DR_OK;
+}
+
+int dr_group_solver_init(dr_group* g, int S, const float* E, const float* M, int n_mat, const int32_t* mat_of_patch) {
+    GRP(g);
+    for (dr_context* c : g->ctx) { int rc = dr_solver_init(c, S, E, M, n_mat, mat_of_patch); if (rc) return rc; }
+    return DR_OK;
+}
+
+int dr_group_solver_reset(dr_group* g) {
+    GRP(g);
+    for (dr_context* c : g->ctx) { int rc = dr_solver_reset(c); if (rc) return rc; }
+    return DR_OK;
+}
+
+// one pass on every device, then the exchange of the new residual chunks; nothing waits on the host
+static int group_pass(dr_group* g, int conv_mode, float thr) {
+    const int n = (int)g->ctx.size();
+    if (g->rccl) {
+        std::string e = comm_group_start();
+        if (!e.empty()) return fail(DR_ERR_COMM, "%s", e.c_str());
+        int rc = DR_OK;
+        for (int r = 0; r < n && rc == DR_OK; r++) rc = sweep_once(g->ctx[r], conv_mode, thr);     // kernel + this rank's part of the all-gather
+        e = comm_group_end();
+        if (rc) return rc;
+        if (!e.empty()) return fail(DR_ERR_COMM, "%s", e.c_str());
+        return DR_OK;
+    }
+    for (int r = 0; r < n; r++) {
+        dr_context* c = g->ctx[r];
+        int rc = sweep_once(c, conv_mode, thr);          // flips c->cur: the new residual is d_R[c->cur]
+        if (rc) return rc;
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipEventRecord(g->ev_done[r], c->stream));
+    }
+    if (n == 1) return DR_OK;
+    for (int d = 0; d < n; d++) {
+        dr_context* cd = g->ctx[d];
+        HIPCHK(hipSetDevice(cd->device));
+        for (int r = 0; r < n; r++) {
+            if (r == d) continue;
+            dr_context* cr = g->ctx[r];
+            HIPCHK(hipStreamWaitEvent(cd->stream, g->ev_done[r], 0));
+            HIPCHK(hipMemcpyPeerAsync(cd->d_R[cd->cur] + (size_t)r * cd->cstride, cd->device, cr->d_R[cr->cur] + (size_t)r * cr->cstride, cr->device,
+                                      sizeof(float) * cd->cstride, cd->stream));
+        }
+    }
+    return DR_OK;
+}
+
+int dr_group_solver_step(dr_group* g, int n_passes, float* residual_sum_out) {
+    GRP(g);
+    if (n_passes < 0) return fail(DR_ERR_INVALID, "n_passes < 0");
+    for (dr_context* c : g->ctx) {
+        if (!c->have_solver) return fail(DR_ERR_STATE, "dr_group_solver_init has not been called");
+        if (!c->have_F) return fail(DR_ERR_STATE, "form factors not assembled");
+    }
+    for (int k = 0; k < n_passes; k++) { int rc = group_pass(g, 0, 0.0f); if (rc) return rc; }
+    int rc = group_sync(g);
+    if (rc) return rc;
+    if (residual_sum_out) {
+        double sums[DR_MAX_BINS];
+        rc = read_sums(g->ctx[0], sums);
+        if (rc) return rc;
+        double t = 0;
+        for (int s = 0; s < g->ctx[0]->S; s++) t += sums[s];
+        *residual_sum_out = (float)t;
+    }
+    return DR_OK;
+}
+
+int dr_group_solver_converge(dr_group* g, float threshold, int per_bin, int max_iters, int* iters_out) {
+    GRP(g);
+    if (max_iters < 0) return fail(DR_ERR_INVALID, "max_iters < 0");
+    for (dr_context* c : g->ctx) {
+        if (!c->have_solver) return fail(DR_ERR_STATE, "dr_group_solver_init has not been called");
+        if (!c->have_F) return fail(DR_ERR_STATE, "form factors not assembled");
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipMemsetAsync(c->d_ctl, 0, sizeof(int) * 4, c->stream));
+    }
+    dr_context* c0 = g->ctx[0];
+    std::vector<int> cur0;
+    for (dr_context* c : g->ctx) cur0.push_back(c->cur);
+    int queued = 0, ctl[2] = { 0, 0 };
+    const int mode = per_bin ? 2 : 1;
+    for (;;) {
+        const int batch = std::min(c0->check_every, max_iters - queued);
+        for (int k = 0; k < batch; k++) { int rc = group_pass(g, mode, threshold); if (rc) return rc; }
+        queued += batch;
+        if (batch == 0) break;
+        int rc = group_sync(g);
+        if (rc) return rc;
+        HIPCHK(hipSetDevice(c0->device));
+        HIPCHK(hipMemcpy(ctl, c0->d_ctl, sizeof ctl, hipMemcpyDeviceToHost));      // the same on every device
+        if (ctl[1] != 0 || ctl[0] < queued || queued >= max_iters) break;
+    }
+    for (size_t r = 0; r < g->ctx.size(); r++) g->ctx[r]->cur = cur0[r] ^ (ctl[0] & 1);
+    if (iters_out) *iters_out = ctl[0];
+    return DR_OK;
+}
+
+int dr_group_solver_read(dr_group* g, float* B, float* R) {
+    GRP(g);
+    for (size_t r = 0; r < g->ctx.size(); r++) {       // every rank fills its own rows of B; the residual is the same everywhere
+        int rc = dr_solver_read(g->ctx[r], B, r == 0 ? R : nullptr);
+        if (rc) return rc;
+    }
+    return DR_OK;
+}
+
+int dr_group_synchronize(dr_group* g) {
+    GRP(g);
+    return group_sync(g);
 }
 
 }  // extern "C"

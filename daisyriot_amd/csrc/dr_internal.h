@@ -42,6 +42,11 @@ constexpr int BVH_END = 0x7ffffff8;
 constexpr int LEAF_MAX = 2;     // subtrees of up to this many triangles are collapsed into one leaf
                                 // (a leaf is fetched whole: LEAF_MAX x 16 SGPRs)
 
+constexpr int MAX_BINS = 16;    // = DR_MAX_BINS of the ABI
+// Every rank's chunk of the residual buffers ends with MAX_BINS doubles: the per-bin sums of the chunk's residual
+// (check_convergence, vs/Lightning.h:255-261), written by the pass that produced the chunk and carried to the other
+// ranks by the same all-gather -- no extra kernel, collective or host round trip to test for convergence.
+constexpr int RTAIL = 2 * MAX_BINS;   // floats
 constexpr int TILE = 64;        // patch-pair tile edge of the assembly kernel
 constexpr int SHARD_ALIGN = 256; // rows per rank are a multiple of this (sweep column tile)
 
@@ -64,10 +69,22 @@ struct TileParams {
     // o in this rank's rows and t in rank B's is traced by exactly one of the two: by the lower rank when o + t is even,
     // by the higher rank when it is odd.  vx_mode 0: no exchange, every rank traces all pairs that touch its rows.
     // vx_mode 1 (first launch): own x own pairs as always; foreign pairs only when they are this rank's, and their
-    // 64 x 64 ray counts also go to slot (o, t) of `vex`.  vx_mode 2 (second launch, after the slots of all ranks
-    // were gathered): the foreign pairs the other side traced: counts from slot (t, o), F tile written from them.
+    // 64 x 64 ray counts also go to slot [B][o - own tile0][t - B's tile0] of `vsend` (one contiguous block per
+    // destination rank).  Then block B of vsend travels to rank B's vrecv[this rank] (an all-to-all: a rank only
+    // receives what it needs, (world-1) * tiles_per_rank^2 slots).  vx_mode 2 (second launch): the foreign pairs the
+    // other side traced: counts from vrecv[B][t - B's tile0][o - own tile0], F tile written from them.
     int vx_mode, vx_rank, vx_tiles_per_rank;
-    unsigned char* vex;                 // [world * tiles_per_rank][nT][64*64] ray counts, row = tile of the min index
+    unsigned char* vsend;               // [world][tiles_per_rank][tiles_per_rank][64*64] ray counts, row = tile of the min index
+    const unsigned char* vrecv;         // same shape; block B = what rank B traced for this rank
+    // Tile-pair shaft culling (build_shaft_list in geom_kernels.hip): once per workgroup the BVH is cut down to a
+    // short list of node ranges that can meet the hull of the two tiles' boxes; every pair's walk runs over that
+    // list instead of starting at the root.  shaft = 0 switches it off (every walk starts at the root).
+    int shaft;
+    int shaft_min_bytes;      // subtrees up to this many bytes of nodes are listed whole, never split further
+    float shaft_pad_ray;      // growth of a tile's box the rays' end points are checked against
+    float shaft_pad_node;     // growth of a tile's box the shaft is built from (>= pad_ray + the node test's error)
+    float shaft_tol;          // max |coordinate| + diagonal: scale of the rounding tolerance of the plane tests
+    float shaft_near_shrink;  // a node is 'near' a tile when it meets the tile's box shrunk by this fraction of its extent per side
 };
 
 // Which rank traces the tile pair {a, b} whose tiles lie in two different ranks' rows (tiles_per_rank tiles of 64 rows
@@ -87,16 +104,27 @@ struct SweepParams {
     int row0, nrows;  // this rank's rows
     size_t ldF;
     const float* F;
-    const float* Rin;     // [world][S][rpr]
-    float* Rout;          // [world][S][rpr]; this rank writes chunk `rank`
+    size_t cstride;       // floats per rank chunk of a residual buffer: S*rpr + RTAIL
+    const float* Rin;     // [world][cstride]: [S][rpr] residual (bin-major) + the chunk's per-bin sums (MAX_BINS doubles)
+    float* Rout;          // same layout; this rank writes chunk `rank` (residual and sums)
     int rank;
     float* B;             // [S][rpr] local
     const float* M;       // [n_mat][S][S]
     const int* mat;       // [rpr] local material index
     int n_mat;
     int skew;         // per-block start-tile multiplier (0 = every block starts at column 0)
-    int ksplit;       // column splits (1 = fused epilogue; >1 = partial sums + k_sweep_epilogue)
+    int ksplit;       // column ranges (gridDim.y); > 1: partial sums to Gpart, the last range of a row block to finish adds them up
     float* Gpart;     // [ksplit][nrows][S] partial F*R sums when ksplit > 1
+    // in-launch reductions: [0] counts the row blocks whose epilogue is done (the last one adds up blk_sums into the
+    // chunk's tail), [1 + x] the column ranges of row block x that have written their partial sums
+    unsigned* tickets;
+    double* blk_sums;     // [row blocks][S]: sums of the new residual per row block
+    // device-side convergence test (dr_solver_converge): 0 = none; 1 = go on while the sum over all bins > thr
+    // (vs/Lightning.h:145-151); 2 = while any bin's sum > thr (:336-340).  A pass that finds the gathered residual
+    // converged does nothing at all (no write, ctl[1] = 1), nor does any pass after it; every real pass counts itself in ctl[0].
+    int conv_mode;
+    float conv_thr;
+    int* ctl;
     // optional: one bit per block of 32 rows x 256 columns of F, set where the block holds a non-zero; blocks whose
     // bit is clear are not read (null = read everything).  mask_words = 32-bit words per row block.
     const unsigned* tile_mask;
@@ -117,11 +145,13 @@ hipError_t launch_patch_colors(hipStream_t st, const float* B, int nrows, int rp
 hipError_t launch_vertex_colors(hipStream_t st, const float* rgb, int V, const int* off, const int* adj, float* out);
 // builds SweepParams::tile_mask from the resident F shard (reads it once)
 hipError_t launch_tile_mask(hipStream_t st, const float* F, int nrows, size_t ldF, unsigned* mask, int mask_words);
-hipError_t launch_colsums(hipStream_t st, const float* R, int world, int S, int rpr, double* sums);
+// per-bin sums of every chunk of R into the chunk's own tail (after a reset; passes maintain them themselves)
+hipError_t launch_chunk_sums(hipStream_t st, float* R, int world, int S, int rpr, size_t cstride);
+int sweep_row_blocks(int nrows, int S);
 // layout conversion between the ABI's patch-major N x S and the device's bin-major chunks
-hipError_t launch_scatter_rows(hipStream_t st, const float* src_NxS, int N, int S, int rpr, int world,
-                               float* dst_chunks /* [world][S][rpr] */);
-hipError_t launch_gather_rows(hipStream_t st, const float* src_chunks, int N, int S, int rpr, int world,
+hipError_t launch_scatter_rows(hipStream_t st, const float* src_NxS, int N, int S, int rpr, size_t cstride,
+                               float* dst_chunks /* [world][cstride] */);
+hipError_t launch_gather_rows(hipStream_t st, const float* src_chunks, int N, int S, int rpr, size_t cstride,
                               float* dst_NxS);
 
 }  // namespace dr

@@ -434,49 +434,94 @@ __device__ __forceinline__ void integrand_pair(const float* ri, const float* rj,
     fb = stored(accB / rj[19]);
 }
 
-// Walk of the threaded BVH for one wave of rays (segments [0,tmax] from org along dn); returns the
-// liveness mask with every lane cleared whose closest hit is not its destination `hi` (wave-uniform: one pair
-// per wave).
+// The two node register sets of the hand-written walk.  They are named, not allocated (the s_load_dwordx8 needs an
+// aligned tuple and the node test its single dwords), and the kernel's SGPR count is at least the highest one named:
+// keep them low -- 256-thread blocks are admitted per CU by the SGPR count in steps of 16 (MI355X_MICROARCH.md,
+// "Residency": <= 80 -> 8, <= 96 -> 7, above -> 6).  tests/test_abi_cpu.py checks the built code object's count.
+#ifndef DR_WALK_SGPR_BASE_HIGH
+#define DR_A_ALL "s[56:63]"
+#define DR_B_ALL "s[48:55]"
+#define DR_A0 "s56"
+#define DR_A1 "s57"
+#define DR_A2 "s58"
+#define DR_A3 "s59"
+#define DR_A4 "s60"
+#define DR_A5 "s61"
+#define DR_A6 "s62"
+#define DR_A7 "s63"
+#define DR_B0 "s48"
+#define DR_B1 "s49"
+#define DR_B2 "s50"
+#define DR_B3 "s51"
+#define DR_B4 "s52"
+#define DR_B5 "s53"
+#define DR_B6 "s54"
+#define DR_B7 "s55"
+#define DR_WALK_CLOBBERS "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63"
+#else
+#define DR_A_ALL "s[88:95]"
+#define DR_B_ALL "s[80:87]"
+#define DR_A0 "s88"
+#define DR_A1 "s89"
+#define DR_A2 "s90"
+#define DR_A3 "s91"
+#define DR_A4 "s92"
+#define DR_A5 "s93"
+#define DR_A6 "s94"
+#define DR_A7 "s95"
+#define DR_B0 "s80"
+#define DR_B1 "s81"
+#define DR_B2 "s82"
+#define DR_B3 "s83"
+#define DR_B4 "s84"
+#define DR_B5 "s85"
+#define DR_B6 "s86"
+#define DR_B7 "s87"
+#define DR_WALK_CLOBBERS "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95"
+#endif
+
+// Walk of one RANGE [off, end) of the threaded BVH for one wave of rays (segments [0,tmax] from org along dn);
+// returns the liveness mask with every lane cleared for which something in the range precedes its destination `hi`
+// (wave-uniform: one pair per wave).  A range is a run of whole subtrees that lie one after the other in the
+// pre-order array (the whole tree is the range [0, n_nodes*32)); every way out of a subtree lands exactly on the
+// first node after it, so leaving the range is only possible on a skip or after a leaf -- those two places compare
+// the offset with `end`, an entered interior node never does.
 //
 // The node index is wave-uniform.  The compiler's lowering of this loop spent ~20 scalar instructions per
 // node (the CU's single scalar unit serves all four SIMDs) beside the vector ones, so the interior-node
 // walk is written out by hand: one s_load_dwordx8 of the node at an SGPR byte offset, the 14-instruction
 // node test (node_hit_mask), one s_and with the liveness mask whose SCC is the branch condition, then
 // either offset += 32 (descend: the first child is the next node in pre-order) or offset = skip --
-// 7 scalar instructions for a node that is entered, 6 for one that is skipped.  There is no end-of-tree
-// compare: skips that leave the tree land on the sentinel node (all-space box, leaf code BVH_END), which
-// every live lane hits; the hand-written stretch ends whenever a hit node is a leaf.
-template <bool STATS>
-__device__ __forceinline__ unsigned long long walk_bvh(const BvhNode* __restrict__ bvh, const TriRec* __restrict__ tri_sorted,
-                                                       int n_nodes_i, f3 org, f3 dn, f3 inv, float tmax, int hi,
-                                                       unsigned long long alive_m, int& n_visit, int& n_leaf) {
-    if (alive_m == 0ull) return 0ull;
-    // per-ray constants of the node test
-    const f3 iv = f3{ __builtin_amdgcn_fmed3f(inv.x, -1e18f, 1e18f), __builtin_amdgcn_fmed3f(inv.y, -1e18f, 1e18f),
-                      __builtin_amdgcn_fmed3f(inv.z, -1e18f, 1e18f) };
-    const f3 kk = f3{ -(org.x * iv.x), -(org.y * iv.y), -(org.z * iv.z) };
-    unsigned off = 0u;          // byte offset of the next node to visit
+// 7 scalar instructions for a node that is entered, 8 for one that is skipped.  The hand-written stretch
+// ends whenever a hit node is a leaf or the range is left.
+//
+// iv / kk: the per-ray constants of the node test (the ray's 1/d clamped to +-1e18, and -(org*iv)).
+template <bool STATS, bool RANGE>
+__device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restrict__ bvh, const TriRec* __restrict__ tri_sorted,
+                                                         unsigned off, const unsigned end, f3 org, f3 dn, f3 inv, f3 iv, f3 kk,
+                                                         float tmax, int hi, unsigned long long alive_m, int& n_visit, int& n_leaf) {
     for (;;) {
+        if (RANGE && off >= end) break;
         int leaf;
         if (STATS) {
             // counted variant of the same walk (debug builds only)
-            for (;;) {
+            leaf = BVH_END;
+            while (off < end) {
                 const v8f raw = *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(bvh) + off);
                 const float nc[3] = { raw[0], raw[1], raw[2] }, nh[3] = { raw[3], raw[4], raw[5] };
                 const unsigned nd_skip = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
-                leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
+                const int nd_leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
                 n_visit++;
                 const unsigned long long hb_m = node_hit_mask(nc, nh, iv, kk, tmax) & alive_m;
                 if (hb_m == 0ull) { off = nd_skip; continue; }
                 off += 32u;
-                if (leaf >= 0) break;
+                if (nd_leaf >= 0) { leaf = nd_leaf; break; }
             }
-            (void)n_nodes_i;
         } else {
             float t0, t1, t2, t3, t4, t5;
-            // two copies of the step, on node registers A = s[88:95] and B = s[80:87]: while one node is tested the
-            // next one in pre-order (the first child, where a hit descends to) is already being fetched into the
-            // other set; a miss reloads its own set from the skip offset.
+            // two copies of the step, on node registers A and B (8 SGPRs each, fixed: DR_WALK_A/B below): while one node
+            // is tested the next one in pre-order (the first child, where a hit descends to) is already being fetched
+            // into the other set; a miss reloads its own set from the skip offset (RANGE: unless that leaves the range).
 #define DR_NODE_TEST(CX, CY, CZ, HX, HY, HZ)                                  \
                 "v_fma_f32 %[t0], " CX ", %[ix], %[kx]\n\t"                   \
                 "v_fma_f32 %[t1], " CY ", %[iy], %[ky]\n\t"                   \
@@ -493,52 +538,62 @@ __device__ __forceinline__ unsigned long long walk_bvh(const BvhNode* __restrict
                 "v_min_f32_e32 %[t0], %[t0], %[tmax]\n\t"                     \
                 "v_cmp_le_f32_e32 vcc, %[t3], %[t0]\n\t"                      \
                 "s_and_b64 vcc, vcc, %[alive]\n\t"
-            asm volatile(
-                "s_load_dwordx8 s[88:95], %[bvh], %[off] offset:0x0\n\t"
-                "s_waitcnt lgkmcnt(0)\n"
-                "1:\n\t"
-                "s_load_dwordx8 s[80:87], %[bvh], %[off] offset:0x20\n\t"
-                DR_NODE_TEST("s88", "s89", "s90", "s91", "s92", "s93")
-                "s_cbranch_scc0 3f\n\t"
-                "s_add_u32 %[off], %[off], 32\n\t"
-                "s_cmp_lt_i32 s95, 0\n\t"
-                "s_cbranch_scc0 5f\n\t"
-                "s_waitcnt lgkmcnt(0)\n"
-                "2:\n\t"
-                "s_load_dwordx8 s[88:95], %[bvh], %[off] offset:0x20\n\t"
-                DR_NODE_TEST("s80", "s81", "s82", "s83", "s84", "s85")
-                "s_cbranch_scc0 4f\n\t"
-                "s_add_u32 %[off], %[off], 32\n\t"
-                "s_cmp_lt_i32 s87, 0\n\t"
-                "s_cbranch_scc0 6f\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "s_branch 1b\n"
-                "3:\n\t"
-                "s_mov_b32 %[off], s94\n\t"
-                "s_load_dwordx8 s[88:95], %[bvh], %[off] offset:0x0\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "s_branch 1b\n"
-                "4:\n\t"
-                "s_mov_b32 %[off], s86\n\t"
-                "s_load_dwordx8 s[80:87], %[bvh], %[off] offset:0x0\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "s_branch 2b\n"
-                "5:\n\t"
-                "s_mov_b32 %[leaf], s95\n\t"
-                "s_branch 7f\n"
-                "6:\n\t"
-                "s_mov_b32 %[leaf], s87\n"
-                "7:\n\t"
-                "s_waitcnt lgkmcnt(0)"
-                : [off] "+s"(off), [leaf] "=s"(leaf), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
-                  [t4] "=&v"(t4), [t5] "=&v"(t5)
-                : [bvh] "s"(bvh), [alive] "s"(alive_m), [kx] "v"(kk.x), [ky] "v"(kk.y), [kz] "v"(kk.z), [ix] "v"(iv.x),
-                  [iy] "v"(iv.y), [iz] "v"(iv.z), [tmax] "v"(tmax)
-                : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94",
-                  "s95", "vcc", "scc");
+#define DR_WALK_ASM(CHECK)                                                                                              \
+            asm volatile(                                                                                               \
+                "s_load_dwordx8 " DR_A_ALL ", %[bvh], %[off] offset:0x0\n\t"                                            \
+                "s_waitcnt lgkmcnt(0)\n"                                                                                \
+                "1:\n\t"                                                                                                \
+                "s_load_dwordx8 " DR_B_ALL ", %[bvh], %[off] offset:0x20\n\t"                                           \
+                DR_NODE_TEST(DR_A0, DR_A1, DR_A2, DR_A3, DR_A4, DR_A5)                                                  \
+                "s_cbranch_scc0 3f\n\t"                                                                                 \
+                "s_add_u32 %[off], %[off], 32\n\t"                                                                      \
+                "s_cmp_lt_i32 " DR_A7 ", 0\n\t"                                                                         \
+                "s_cbranch_scc0 5f\n\t"                                                                                 \
+                "s_waitcnt lgkmcnt(0)\n"                                                                                \
+                "2:\n\t"                                                                                                \
+                "s_load_dwordx8 " DR_A_ALL ", %[bvh], %[off] offset:0x20\n\t"                                           \
+                DR_NODE_TEST(DR_B0, DR_B1, DR_B2, DR_B3, DR_B4, DR_B5)                                                  \
+                "s_cbranch_scc0 4f\n\t"                                                                                 \
+                "s_add_u32 %[off], %[off], 32\n\t"                                                                      \
+                "s_cmp_lt_i32 " DR_B7 ", 0\n\t"                                                                         \
+                "s_cbranch_scc0 6f\n\t"                                                                                 \
+                "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+                "s_branch 1b\n"                                                                                         \
+                "3:\n\t"                                                                                                \
+                "s_mov_b32 %[off], " DR_A6 "\n\t"                                                                       \
+                CHECK                                                                                                   \
+                "s_load_dwordx8 " DR_A_ALL ", %[bvh], %[off] offset:0x0\n\t"                                            \
+                "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+                "s_branch 1b\n"                                                                                         \
+                "4:\n\t"                                                                                                \
+                "s_mov_b32 %[off], " DR_B6 "\n\t"                                                                       \
+                CHECK                                                                                                   \
+                "s_load_dwordx8 " DR_B_ALL ", %[bvh], %[off] offset:0x0\n\t"                                            \
+                "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+                "s_branch 2b\n"                                                                                         \
+                "5:\n\t"                                                                                                \
+                "s_mov_b32 %[leaf], " DR_A7 "\n\t"                                                                      \
+                "s_branch 7f\n"                                                                                         \
+                "6:\n\t"                                                                                                \
+                "s_mov_b32 %[leaf], " DR_B7 "\n\t"                                                                      \
+                "s_branch 7f\n"                                                                                         \
+                "8:\n\t"                                                                                                \
+                "s_mov_b32 %[leaf], 0x7ffffff8\n"                                                                       \
+                "7:\n\t"                                                                                                \
+                "s_waitcnt lgkmcnt(0)"                                                                                  \
+                : [off] "+s"(off), [leaf] "=s"(leaf), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),   \
+                  [t4] "=&v"(t4), [t5] "=&v"(t5)                                                                        \
+                : [bvh] "s"(bvh), [alive] "s"(alive_m), [end] "s"(end), [kx] "v"(kk.x), [ky] "v"(kk.y), [kz] "v"(kk.z), \
+                  [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z), [tmax] "v"(tmax)                                      \
+                : DR_WALK_CLOBBERS, "vcc", "scc")
+            // without ranges there is no end compare at all: skips that leave the tree land on the sentinel node
+            // (all-space box, leaf code BVH_END), which every live lane hits
+            if (RANGE) { DR_WALK_ASM("s_cmp_lt_u32 %[off], %[end]\n\ts_cbranch_scc0 8f\n\t"); }
+            else { DR_WALK_ASM(""); }
+#undef DR_WALK_ASM
 #undef DR_NODE_TEST
         }
-        if (leaf == BVH_END) break;
+        if (leaf == BVH_END) break;          // the range is done (or the tree's sentinel was reached)
         if (STATS) n_leaf++;
         const int first = leaf >> 3, cnt = (leaf & 3) + 1;
         const bool same_gate = (leaf & 4) != 0;          // both triangles share one gate box (the halves of a quad)
@@ -576,10 +631,147 @@ __device__ __forceinline__ unsigned long long walk_bvh(const BvhNode* __restrict
     return alive_m;
 }
 
+// ---------------------------------------------------------------------------------------
+// Tile-pair shaft culling.
+//
+// All K rays of all 64 x 64 pairs of a tile pair run from a point of tile I's patches to a point of tile J's, so they
+// stay inside the convex hull of the two tiles' bounding boxes (the "shaft"; Haines & Wallace 1994).  Once per
+// workgroup one wave walks the BVH against the shaft and cuts it down to a short list of node RANGES (runs of whole
+// subtrees) that can meet it; every pair's walk (walk_range) then runs over that list instead of starting at the
+// root -- it neither re-tests, 4096 times over, the ancestors every one of these rays is inside of, nor whatever lies
+// outside the shaft.
+//
+// Exactness.  What is hit is decided per triangle by its gate and the Moller-Trumbore test, whichever way a walk got
+// to the triangle's leaf; so a walk over the list gives the brute-force answer as long as it reaches every leaf the
+// walk from the root would reach.  The walk from the root reaches a leaf iff the ray's node test accepts every
+// ancestor; that test accepts a node only if the (real-arithmetic) segment org + t*dn, t in [0,tmax] passes within
+// 1e-6*(M + D) of the node's stored box in every axis (its fma roundings are <= 6 ulp of (|c|+|org|+h)|iv|; M = max
+// |coordinate|, D = scene diagonal).  The list keeps every node whose box meets the hull of the two tile boxes grown
+// by shaft_pad_node = 5e-6*(M + D), tested with a further tolerance for the test's own roundings; and a pair only
+// uses the list when, for every live ray, the origin lies in tile I's box and the end point org + tmax*dn in tile J's
+// (each grown by shaft_pad_ray = 1e-6*(M + D)) -- checked on the very floats the walk uses, so a ray whose tmax is
+// rounding noise (a grazing destination) or whose origin offset leaves the box simply sends its pair down the walk
+// from the root.  Hence segment in hull(I', J'), accepted node within 1e-6*(M+D) of the segment => node kept.
+//
+// The shaft's planes: the six faces of the union box, and up to 12 "connecting" planes, each holding an edge of box
+// I and the parallel edge of box J: per axis a and corner type (sp, sq) of the boxes' projections along a, the plane
+// through corner(sp,sq) of both rectangles with normal (sp*|dq|, sq*|dp|) -- a supporting plane of both iff dp*sp and
+// dq*sq have opposite signs.  With d0 = max(n.cornerI, n.cornerJ), the half-space n.x <= d0 holds both boxes for ANY n
+// of that sign pattern (the support point of a box in such a direction IS that corner), so rounding in n is harmless;
+// rounding in the dot products is covered by the tolerance 1e-5*|n|_1*(M + D).
+// ---------------------------------------------------------------------------------------
+constexpr int LIST_MAX = 96;             // ranges per tile pair; more than that: the walks start at the root
+constexpr unsigned long long SHAFT_CULL = 0x3ffffull;        // lanes 0-11 connecting planes, 12-17 union box
+constexpr int SHAFT_NEAR_I = 18, SHAFT_NEAR_J = 24;           // lanes 18-23: tile I's box, 24-29: tile J's
+
+struct ShaftLane { float nx, ny, nz, d0; bool valid; };
+
+__device__ __forceinline__ float pick3(f3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+__device__ __forceinline__ f3 sel3(bool c, f3 a, f3 b) { return f3{ c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z }; }
+
+// per-lane plane of the shaft test; I / J = the two tile boxes grown by shaft_pad_node
+__device__ __forceinline__ ShaftLane shaft_lane(int l, f3 Ilo, f3 Ihi, f3 Jlo, f3 Jhi, float tol_scale, float near_shrink) {
+    ShaftLane L;
+    float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
+    L.d0 = 0.0f; L.valid = false;
+    if (l < 12) {
+        const int a = l >> 2, p = a == 2 ? 0 : a + 1, q = a == 0 ? 2 : a - 1;
+        const bool hp = (l & 1) != 0, hq = (l & 2) != 0;
+        const float sp = hp ? 1.0f : -1.0f, sq = hq ? 1.0f : -1.0f;
+        const float Ap = pick3(sel3(hp, Ihi, Ilo), p), Aq = pick3(sel3(hq, Ihi, Ilo), q);
+        const float Bp = pick3(sel3(hp, Jhi, Jlo), p), Bq = pick3(sel3(hq, Jhi, Jlo), q);
+        const float dp = Bp - Ap, dq = Bq - Aq;
+        const float a1 = dp * sp, a2 = dq * sq;
+        L.valid = (a1 > 0.0f && a2 < 0.0f) || (a1 < 0.0f && a2 > 0.0f);
+        const float sc = 1.0f / fmaxf(fmaxf(fabsf(dp), fabsf(dq)), 1e-30f);
+        const float np_ = sp * (fabsf(dq) * sc), nq_ = sq * (fabsf(dp) * sc);
+        L.valid = L.valid && (np_ != 0.0f) && (nq_ != 0.0f);      // an underflowed component would change the sign pattern
+        L.d0 = fmaxf(np_ * Ap + nq_ * Aq, np_ * Bp + nq_ * Bq);
+        n0 = p == 0 ? np_ : (q == 0 ? nq_ : 0.0f);
+        n1 = p == 1 ? np_ : (q == 1 ? nq_ : 0.0f);
+        n2 = p == 2 ? np_ : (q == 2 ? nq_ : 0.0f);
+    } else if (l < 30) {
+        const int k = (l - 12) % 6, which = (l - 12) / 6;          // 0 union, 1 tile I, 2 tile J
+        const int a = k >> 1;
+        const bool pos = (k & 1) != 0;
+        const float ilo = pick3(Ilo, a), ihi = pick3(Ihi, a), jlo = pick3(Jlo, a), jhi = pick3(Jhi, a);
+        float lo = which == 0 ? fminf(ilo, jlo) : (which == 1 ? ilo : jlo);
+        float hi = which == 0 ? fmaxf(ihi, jhi) : (which == 1 ? ihi : jhi);
+        if (which != 0) {       // "near a tile" = meets the tile's box shrunk towards its middle (a heuristic only: it decides what is split)
+            const float sh = near_shrink * (hi - lo);
+            lo += sh; hi -= sh;
+        }
+        const float sg = pos ? 1.0f : -1.0f;
+        n0 = a == 0 ? sg : 0.0f; n1 = a == 1 ? sg : 0.0f; n2 = a == 2 ? sg : 0.0f;
+        L.d0 = pos ? hi : -lo;
+        L.valid = true;
+    }
+    L.nx = n0; L.ny = n1; L.nz = n2;
+    L.d0 += 1e-5f * ((fabsf(n0) + fabsf(n1)) + fabsf(n2)) * tol_scale;
+    return L;
+}
+
+// which of the lanes' planes have the node's box entirely on their outer side
+__device__ __forceinline__ unsigned long long shaft_out_mask(const ShaftLane& L, const v8f nd) {
+    const float s = ((L.nx * nd[0] + L.ny * nd[1]) + L.nz * nd[2]) - ((fabsf(L.nx) * nd[3] + fabsf(L.ny) * nd[4]) + fabsf(L.nz) * nd[5]);
+    return __builtin_amdgcn_ballot_w64(L.valid && (s > L.d0));
+}
+
+__device__ __forceinline__ v8f load_node(const BvhNode* bvh, unsigned off) {
+    return *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(bvh) + off);
+}
+
+// One wave (all 64 lanes, uniform control flow).  Writes the ranges to sList and returns their number;
+// stats[0] += nodes looked at.
+__device__ __forceinline__ int build_shaft_list(const BvhNode* __restrict__ bvh, unsigned end_all, f3 Ilo, f3 Ihi, f3 Jlo, f3 Jhi,
+                                                float tol_scale, float near_shrink, unsigned min_bytes, uint2* sList, int lane, int& n_looked) {
+    const ShaftLane L = shaft_lane(lane, Ilo, Ihi, Jlo, Jhi, tol_scale, near_shrink);
+    unsigned off = 0u, prev_end = 0xffffffffu;
+    int n = 0;
+    bool overflow = false;
+    while (off < end_all) {
+        const v8f nd = load_node(bvh, off);
+        const unsigned skip = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(nd[6]));
+        const int tri = __builtin_amdgcn_readfirstlane(__float_as_int(nd[7]));
+        const unsigned long long m = shaft_out_mask(L, nd);
+        n_looked++;
+        if (m & SHAFT_CULL) { off = skip; continue; }           // outside the shaft: nothing below it can be touched
+        bool emit = true;
+        if (tri < 0 && skip - off > min_bytes) {
+            // split a big subtree when that prunes: always near the two tiles (every ray is inside these nodes, their
+            // tests are pure overhead), elsewhere when a child lies outside the shaft
+            const bool near = ((m >> SHAFT_NEAR_I) & 0x3full) == 0ull || ((m >> SHAFT_NEAR_J) & 0x3full) == 0ull;
+            if (near) emit = false;
+            else {
+                const v8f c0 = load_node(bvh, off + 32u);
+                const unsigned c1_off = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(c0[6]));
+                const v8f c1 = load_node(bvh, c1_off);
+                n_looked += 2;
+                if ((shaft_out_mask(L, c0) & SHAFT_CULL) || (shaft_out_mask(L, c1) & SHAFT_CULL)) emit = false;
+            }
+        }
+        if (!emit) { off += 32u; continue; }
+        if (n > 0 && prev_end == off) {
+            if (lane == 0) sList[n - 1].y = skip;               // runs on from the previous range
+        } else {
+            if (n == LIST_MAX) { overflow = true; break; }
+            if (lane == 0) sList[n] = make_uint2(off, skip);
+            n++;
+        }
+        prev_end = skip;
+        off = skip;
+    }
+    if (overflow) {
+        if (lane == 0) sList[0] = make_uint2(0u, end_all);
+        n = 1;
+    }
+    return n;
+}
+
 // STATS builds count BVH visits with global atomics inside the pair loop; that store makes
 // the compiler give up scalar (SMEM) loads for nodes and triangles, so it is a separate,
 // debug-only instantiation.
-template <int NT, bool STATS>
+template <int NT, bool STATS, bool SHAFT>
 __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
     const int t = blockIdx.x;
     const int o = P.tile0 + blockIdx.y;
@@ -606,6 +798,9 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
     __shared__ unsigned char sVis[TILE][VIS_STRIDE];   // ray count per pair, 255 = not traced
     __shared__ unsigned short sQueue[TILE * TILE];
     __shared__ int sCount;
+    __shared__ float sBox[2][6];                        // union of the gate boxes of the I / J tile's patches: lo[3], hi[3]
+    __shared__ uint2 sList[LIST_MAX];                   // the tile pair's candidate node ranges (build_shaft_list)
+    __shared__ int sNList;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -617,11 +812,30 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
         int g = (side ? J0 : I0) + r;
         sRec[side][r][c] = (g < P.N) ? reinterpret_cast<const float*>(P.patch + g)[c] : 0.0f;
     }
+    if (SHAFT && tid < 2 * TILE) {
+        // bounding boxes of the two tiles (waves 0 and 1): every ray of the tile pair starts in one and ends in the other
+        const int side = tid >> 6;
+        const int g = (side ? J0 : I0) + lane;
+        float b[6] = { INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY };
+        if (g < P.N) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) { b[a] = P.tri[g].lo[a]; b[3 + a] = P.tri[g].hi[a]; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+            for (int a = 0; a < 3; a++) { b[a] = fminf(b[a], __shfl_xor(b[a], o)); b[3 + a] = fmaxf(b[3 + a], __shfl_xor(b[3 + a], o)); }
+        if (lane == 0) {
+#pragma unroll
+            for (int a = 0; a < 6; a++) sBox[side][a] = b[a];
+        }
+    }
     __syncthreads();
 
     if (from_slot) {
         // the other rank traced this pair: its counts, in the same orientation (rows = the tile of the lower index)
-        const unsigned char* slot = P.vex + ((size_t)t * P.nT + o) * (TILE * TILE);
+        const int T = P.vx_tiles_per_rank, B = t / T;
+        const unsigned char* slot = P.vrecv + (((size_t)B * T + (t - B * T)) * T + (o - P.tile0)) * (TILE * TILE);
         for (int p = tid; p < TILE * TILE; p += NT) sVis[p >> 6][p & 63] = slot[p];
     }
     // ---- which pairs are traced: stored integrand lo->hi > 0 (vs/OptixPrimeFunctionality.cpp:190)
@@ -646,12 +860,35 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
     }
     __syncthreads();
     const int n_act = sCount;
+    const unsigned end_all = (unsigned)P.n_nodes * (unsigned)sizeof(BvhNode);
+
+    // ---- the tile pair's shaft: the node ranges its walks run over --------------------------------
+    const bool use_shaft = SHAFT && (n_act > 0) && (P.trace != 0);
+    if (use_shaft) {
+        if (tid < 64) {
+            const float pn = P.shaft_pad_node;
+            const f3 Ilo = f3{ sBox[0][0] - pn, sBox[0][1] - pn, sBox[0][2] - pn }, Ihi = f3{ sBox[0][3] + pn, sBox[0][4] + pn, sBox[0][5] + pn };
+            const f3 Jlo = f3{ sBox[1][0] - pn, sBox[1][1] - pn, sBox[1][2] - pn }, Jhi = f3{ sBox[1][3] + pn, sBox[1][4] + pn, sBox[1][5] + pn };
+            int n_looked = 0;
+            const int nl = build_shaft_list(P.bvh, end_all, Ilo, Ihi, Jlo, Jhi, P.shaft_tol, P.shaft_near_shrink, (unsigned)P.shaft_min_bytes, sList, lane, n_looked);
+            if (lane == 0) {
+                sNList = nl;
+                if (STATS && P.dbg_lo < 0) {
+                    atomicAdd(P.pairs_traced + 8, (unsigned long long)nl);
+                    atomicAdd(P.pairs_traced + 9, (unsigned long long)n_looked);
+                    atomicAdd(P.pairs_traced + 11, 1ull);
+                }
+            }
+        }
+        __syncthreads();
+    }
 
     // ---- visibility: one wave per pair, one lane per ray, wave-uniform BVH walk ---------
     if (n_act > 0 && P.trace) {
         // queue entries are dealt round-robin to the block's waves (all indices wave-uniform)
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int n_act_u = __builtin_amdgcn_readfirstlane(n_act);
+        const int n_list = use_shaft ? __builtin_amdgcn_readfirstlane(sNList) : 1;
         for (int q = wave; q < n_act_u; q += NT / 64) {
             const int p = __builtin_amdgcn_readfirstlane((int)sQueue[q]);
             const int i = p >> 6, j = p & 63;
@@ -683,7 +920,34 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
                 alive = alive && ((box_hit_mask(Th.lo, Th.hi, org, inv, INFINITY) >> lane) & 1ull);
                 unsigned long long alive_m = __builtin_amdgcn_ballot_w64(alive);
                 if (STATS && lo == P.dbg_lo && hi == P.dbg_hi && lane == 0) P.pairs_traced[1] = alive_m;
-                alive_m = walk_bvh<STATS>(P.bvh, P.tri_sorted, P.n_nodes, org, dn, inv, tmax, hi, alive_m, n_visit, n_leaf);
+                if (alive_m != 0ull) {
+                    // per-ray constants of the node test
+                    const f3 iv = f3{ __builtin_amdgcn_fmed3f(inv.x, -1e18f, 1e18f), __builtin_amdgcn_fmed3f(inv.y, -1e18f, 1e18f),
+                                      __builtin_amdgcn_fmed3f(inv.z, -1e18f, 1e18f) };
+                    const f3 kk = f3{ -(org.x * iv.x), -(org.y * iv.y), -(org.z * iv.z) };
+                    // The list only serves rays that really run from tile I's box to tile J's (see "Exactness" above):
+                    // one ray outside (a tmax that is rounding noise, an origin offset that leaves the box) and this
+                    // pair walks from the root.
+                    bool from_root = !use_shaft;
+                    if (use_shaft) {
+                        const f3 ep = f3{ __builtin_fmaf(dn.x, tmax, org.x), __builtin_fmaf(dn.y, tmax, org.y), __builtin_fmaf(dn.z, tmax, org.z) };
+                        const float pr = P.shaft_pad_ray;
+                        bool inb = (org.x >= sBox[0][0] - pr) & (org.y >= sBox[0][1] - pr) & (org.z >= sBox[0][2] - pr) &
+                                   (org.x <= sBox[0][3] + pr) & (org.y <= sBox[0][4] + pr) & (org.z <= sBox[0][5] + pr) &
+                                   (ep.x >= sBox[1][0] - pr) & (ep.y >= sBox[1][1] - pr) & (ep.z >= sBox[1][2] - pr) &
+                                   (ep.x <= sBox[1][3] + pr) & (ep.y <= sBox[1][4] + pr) & (ep.z <= sBox[1][5] + pr);
+                        from_root = (__builtin_amdgcn_ballot_w64(alive && !inb) != 0ull);
+                        if (STATS && from_root && lane == 0 && P.dbg_lo < 0) atomicAdd(P.pairs_traced + 10, 1ull);
+                    }
+                    const int ne = from_root ? 1 : n_list;
+                    for (int e = 0; e < ne; e++) {
+                        const uint2 rg = sList[e];
+                        const unsigned r_off = from_root ? 0u : (unsigned)__builtin_amdgcn_readfirstlane((int)rg.x);
+                        const unsigned r_end = from_root ? end_all : (unsigned)__builtin_amdgcn_readfirstlane((int)rg.y);
+                        alive_m = walk_range<STATS, SHAFT>(P.bvh, P.tri_sorted, r_off, r_end, org, dn, inv, iv, kk, tmax, hi, alive_m, n_visit, n_leaf);
+                        if (alive_m == 0ull) break;
+                    }
+                }
                 count += __popcll(alive_m);
                 if (STATS && lo == P.dbg_lo && hi == P.dbg_hi && lane == 0) P.pairs_traced[3] = alive_m;
             }
@@ -698,7 +962,8 @@ __global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
     if (tid == 0 && n_act > 0 && P.trace && P.pairs_traced) atomicAdd(P.pairs_traced, (unsigned long long)n_act);
     if (P.vx_mode == 1 && !t_owned) {
         // this pair is also the other rank's: hand its ray counts over (slot of own tile o, foreign tile t)
-        unsigned char* slot = P.vex + ((size_t)o * P.nT + t) * (TILE * TILE);
+        const int T = P.vx_tiles_per_rank, B = t / T;
+        unsigned char* slot = P.vsend + (((size_t)B * T + (o - P.tile0)) * T + (t - B * T)) * (TILE * TILE);
         for (int p = tid; p < TILE * TILE; p += NT) slot[p] = sVis[p >> 6][p & 63];
     }
 
@@ -750,13 +1015,18 @@ static int tile_threads() {
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p) {
     dim3 grid(p.nT, p.nOwnedTiles);
     if (p.stats & 1) {
-        hipLaunchKernelGGL((k_ff_tiles<256, true>), grid, dim3(256), 0, st, p);
+        if (p.shaft) hipLaunchKernelGGL((k_ff_tiles<256, true, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_ff_tiles<256, true, false>), grid, dim3(256), 0, st, p);
+        return hipGetLastError();
+    }
+    if (p.shaft) {
+        hipLaunchKernelGGL((k_ff_tiles<256, false, true>), grid, dim3(256), 0, st, p);
         return hipGetLastError();
     }
     switch (tile_threads()) {
-        case 512: hipLaunchKernelGGL((k_ff_tiles<512, false>), grid, dim3(512), 0, st, p); break;
-        case 1024: hipLaunchKernelGGL((k_ff_tiles<1024, false>), grid, dim3(1024), 0, st, p); break;
-        default: hipLaunchKernelGGL((k_ff_tiles<256, false>), grid, dim3(256), 0, st, p); break;
+        case 512: hipLaunchKernelGGL((k_ff_tiles<512, false, false>), grid, dim3(512), 0, st, p); break;
+        case 1024: hipLaunchKernelGGL((k_ff_tiles<1024, false, false>), grid, dim3(1024), 0, st, p); break;
+        default: hipLaunchKernelGGL((k_ff_tiles<256, false, false>), grid, dim3(256), 0, st, p); break;
     }
     return hipGetLastError();
 }

@@ -6,8 +6,16 @@
 // residual tile is staged in LDS, and the per-patch S x S transfer is the kernel's epilogue.
 //
 // Layouts (device): F row-major, leading dimension ldF = world*rpr (zero padded);
-// residual R as [world][S][rpr] (rank-major so an in-place all-gather fills it, bin-major
-// inside a chunk so a column tile of one bin is contiguous); B as [S][rpr].
+// residual R as [world][cstride], a chunk = [S][rpr] (rank-major so an in-place all-gather fills it, bin-major
+// inside a chunk so a column tile of one bin is contiguous) followed by the chunk's per-bin sums (RTAIL floats =
+// MAX_BINS doubles); B as [S][rpr].
+//
+// One launch per pass, whatever the shard: when the columns are cut into ranges (small row shards), the last range
+// of a row block to arrive adds the partial sums in range order and runs the epilogue (no second kernel); the last
+// row block to finish adds the row blocks' residual sums in a fixed order into the chunk's tail, which the same
+// all-gather carries to every rank; and with a convergence rule in SweepParams each pass first looks at the tails
+// of the residual it was given and does nothing if that has converged -- dr_solver_converge queues passes without
+// a host round trip per pass (check_convergence, vs/Lightning.h:145-151, 255-261, 336-340).
 #include "dr_internal.h"
 
 #include <cstdlib>
@@ -16,17 +24,133 @@ namespace dr {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// Has the gathered residual Rin converged under the pass's rule?  Every block of every rank reads the same
+// world x S doubles and adds them in the same order: the whole job takes the same decision.
+__device__ __forceinline__ bool residual_converged(const SweepParams& P) {
+    double tot = 0.0;
+    bool any = false;
+    for (int s = 0; s < P.S; s++) {
+        double t = 0.0;
+        for (int c = 0; c < P.world; c++)
+            t += reinterpret_cast<const double*>(P.Rin + (size_t)c * P.cstride + (size_t)P.S * P.rpr)[s];
+        any = any || (t > (double)P.conv_thr);
+        tot += t;
+    }
+    return P.conv_mode == 2 ? !any : !(tot > (double)P.conv_thr);
+}
+
+// one arrival at a counter that `expected` blocks arrive at; true for the block that arrives last (it also rearms the
+// counter for the next pass).  Everything the block wrote before is visible to whoever sees its arrival (agent-scope
+// release before, acquire after: MI355X_MICROARCH.md, "Workgroup dispatch ... inter-workgroup visibility").
+__device__ __forceinline__ bool arrive_last(unsigned* counter, unsigned expected, int* sFlag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = atomicAdd(counter, 1u);
+        const bool last = (t == expected - 1u);
+        if (last) atomicExch(counter, 0u);      // through the same path as the adds
+        *sFlag = last ? 1 : 0;
+    }
+    __syncthreads();
+    const bool last = *sFlag != 0;
+    if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    return last;
+}
+
+// What follows the stream over F in both pass kernels.  sGf[ROWSB][SPAD] (LDS) holds the block's rows' sums F*R over
+// its column range.  SPLIT: those are partial -- written out, and the last range of the row block to arrive adds all
+// ranges up in range order (bit-stable).  Then the epilogue: R' = M_mat * G (per-patch S x S bin transfer,
+// vs/Lightning.h:205-218), residual out, B += R'; the row block's per-bin sums of R' (rows in order, double); and the
+// last row block adds those up (16 interleaved partial sums per bin, then these in order) into the chunk's tail.
+template <int ROWSB, int SPAD, int NT, bool SPLIT>
+__device__ __forceinline__ void sweep_tail(const SweepParams& P, float* sGf, float* sV /* [S][ROWSB] */, double* sD /* [256] */,
+                                           int* sFlag) {
+    static_assert(NT >= 256, "the final reduction uses 256 threads");
+    const int tid = threadIdx.x;
+    const int S = P.S;
+    const int row0b = blockIdx.x * ROWSB;
+    if (SPLIT) {
+        for (int e = tid; e < ROWSB * S; e += NT) {
+            const int rl = e / S, s2 = e % S;
+            const int row = row0b + rl;
+            if (row < P.nrows) P.Gpart[((size_t)blockIdx.y * P.nrows + row) * S + s2] = sGf[rl * SPAD + s2];
+        }
+        if (!arrive_last(&P.tickets[1 + blockIdx.x], gridDim.y, sFlag)) return;
+        for (int e = tid; e < ROWSB * S; e += NT) {
+            const int rl = e / S, s2 = e % S;
+            const int row = row0b + rl;
+            float g = 0.0f;
+            if (row < P.nrows)
+                for (int k = 0; k < (int)gridDim.y; k++) g += P.Gpart[((size_t)k * P.nrows + row) * S + s2];
+            sGf[rl * SPAD + s2] = g;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < ROWSB * S; e += NT) {
+        const int so = e / ROWSB, rl = e % ROWSB;          // consecutive threads -> consecutive rows of one bin
+        const int row = row0b + rl;
+        float v = 0.0f;
+        if (row < P.nrows) {
+            const float* Mi = P.M + (size_t)P.mat[row] * S * S + so * S;
+            for (int s2 = 0; s2 < S; s2++) v = fmaf(Mi[s2], sGf[rl * SPAD + s2], v);
+            P.Rout[(size_t)P.rank * P.cstride + (size_t)so * P.rpr + row] = v;
+            float* b = P.B + (size_t)so * P.rpr + row;
+            *b = *b + v;
+        }
+        sV[so * ROWSB + rl] = v;
+    }
+    __syncthreads();
+    if (tid < S) {
+        double a = 0.0;
+        for (int rl = 0; rl < ROWSB; rl++) a += (double)sV[tid * ROWSB + rl];
+        P.blk_sums[(size_t)blockIdx.x * S + tid] = a;
+    }
+    if (!arrive_last(&P.tickets[0], gridDim.x, sFlag)) return;
+    if (tid < 256) {
+        const int s2 = tid >> 4, j = tid & 15;
+        double a = 0.0;
+        if (s2 < S)
+            for (int x = j; x < (int)gridDim.x; x += 16) a += P.blk_sums[(size_t)x * S + s2];
+        sD[tid] = a;
+    }
+    __syncthreads();
+    if (tid < S) {
+        double a = 0.0;
+        for (int j = 0; j < 16; j++) a += sD[tid * 16 + j];
+        reinterpret_cast<double*>(P.Rout + (size_t)P.rank * P.cstride + (size_t)S * P.rpr)[tid] = a;
+    }
+    if (tid == 0) P.ctl[0] = P.ctl[0] + 1;
+}
+
 // S bins, RR rows per wave, NW waves per block, CPL float4 column groups per lane per row
 // and tile (tile = 256*CPL columns), NT = non-temporal F loads (F is streamed once; keep
 // the residual, which every block re-reads, resident in L2 instead).
 // SPLIT: the columns are cut into gridDim.y ranges (small row shards would otherwise leave most
-// CUs with one block or none); each block then writes its partial sums and k_sweep_epilogue adds
-// them in a fixed order and applies the bin transfer.
-template <int S, int RR, int NW, int CPL, bool NT, int OCC, bool SPLIT>
+// CUs with one block or none); each block then writes its partial sums and the last range of the row block
+// to arrive adds them in range order and applies the bin transfer (sweep_tail).
+// LIST: the instantiation that can run over a list of non-zero tiles (SweepParams::tile_mask); the dense one does
+// not carry the list's 8 KiB of LDS.
+template <int S, int RR, int NW, int CPL, bool NT, int OCC, bool SPLIT, bool LIST>
 __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
     constexpr int TC = 256 * CPL;
     __shared__ __attribute__((aligned(16))) float sR[2][S][TC];
     __shared__ float sG[NW][RR][S];
+    __shared__ float sV[S][NW * RR];
+    __shared__ double sD[256];
+    __shared__ int sFlag;
+
+    // converged: this pass and every pass queued behind it does nothing (latched in ctl[1]: the host keeps flipping the two
+    // residual buffers per queued pass, and the older of the two has NOT converged)
+    if (P.conv_mode != 0 && (P.ctl[1] != 0 || residual_converged(P))) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.ctl[1] = 1;
+        return;
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -57,7 +181,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
         const int t = tile0 + tl;
         const int chunk = t / tiles_per_chunk;
         const int l0 = (t - chunk * tiles_per_chunk) * TC;
-        const float* base = P.Rin + (size_t)chunk * S * P.rpr + l0;
+        const float* base = P.Rin + (size_t)chunk * P.cstride + l0;
 #pragma unroll
         for (int x = 0; x < R4_PER_THREAD; x++) {
             const int q = tid + x * NW * 64;        // float4 index inside the tile
@@ -93,10 +217,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
     // Optional list of the tiles of this block's range that hold a non-zero in its 32 rows (SweepParams::tile_mask):
     // built in order by one wave; the loop below then runs over the list only -- no loads, no staging, no barrier
     // for a tile that is zero in all of the block's rows.
-    constexpr int MAXT = 4096;
+    constexpr int MAXT = LIST ? 4096 : 1;
     __shared__ unsigned short sTiles[MAXT];
     __shared__ int sNT, sPos;
-    const bool use_list = (RR * NW == 32) && (P.tile_mask != nullptr) && (ntiles <= MAXT);
+    const bool use_list = LIST && (RR * NW == 32) && (P.tile_mask != nullptr) && (ntiles <= MAXT);
     // start tile of this block (launch_sweep picks the skew); with a list: the first listed tile at or after it, so
     // that the non-zero tiles are visited in the same order as without the list (bit-identical sums)
     const int start_tile = (int)(((unsigned)blockIdx.x * (unsigned)P.skew) % (unsigned)ntiles);
@@ -184,28 +308,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
     }
     __syncthreads();
 
-    if (SPLIT) {
-        for (int e = lane; e < RR * S; e += 64) {
-            const int r = e / S, s = e % S;
-            const int row = rbase + r;
-            if (row < P.nrows) P.Gpart[((size_t)blockIdx.y * P.nrows + row) * S + s] = sG[wave][r][s];
-        }
-        return;
-    }
-    // epilogue: per-patch S x S bin transfer, residual out, B += residual
-    for (int e = lane; e < RR * S; e += 64) {
-        const int so = e / RR, r = e % RR;          // consecutive lanes -> consecutive rows of one bin
-        const int row = rbase + r;
-        if (row < P.nrows) {
-            const float* Mi = P.M + (size_t)P.mat[row] * S * S + so * S;
-            float v = 0.0f;
-#pragma unroll
-            for (int s = 0; s < S; s++) v = fmaf(Mi[s], sG[wave][r][s], v);
-            P.Rout[((size_t)P.rank * S + so) * P.rpr + row] = v;
-            float* b = P.B + (size_t)so * P.rpr + row;
-            *b = *b + v;
-        }
-    }
+    sweep_tail<NW * RR, S, NW * 64, SPLIT>(P, &sG[0][0][0], &sV[0][0], sD, &sFlag);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -224,12 +327,21 @@ constexpr int MT_ROWS = 16;     // rows per wave
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-template <int NW, bool SPLIT>
+template <int NW, bool SPLIT, bool LIST>
 __global__ __launch_bounds__(NW * 64) void k_sweep_mfma(SweepParams P) {
     __shared__ __attribute__((aligned(16))) float sF[NW][2][MT_ROWS * MT_TC];      // 16 KiB per wave
     __shared__ __attribute__((aligned(16))) float sRt[(MT_TC / 4) * 16 * 4];       // [chunk][bin][4 columns], 8 KiB
     __shared__ float sG[NW][MT_ROWS][16];
+    __shared__ float sV[MAX_BINS][NW * MT_ROWS];
+    __shared__ double sD[256];
+    __shared__ int sFlag;
 
+    // converged: this pass and every pass queued behind it does nothing (latched in ctl[1]: the host keeps flipping the two
+    // residual buffers per queued pass, and the older of the two has NOT converged)
+    if (P.conv_mode != 0 && (P.ctl[1] != 0 || residual_converged(P))) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.ctl[1] = 1;
+        return;
+    }
     const int S = P.S;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -268,7 +380,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_mfma(SweepParams P) {
         const int t = tile0 + tl;
         const int chunk_rank = t / tiles_per_chunk;
         const int l0 = (t - chunk_rank * tiles_per_chunk) * MT_TC;
-        const float* base = P.Rin + (size_t)chunk_rank * S * P.rpr + l0;
+        const float* base = P.Rin + (size_t)chunk_rank * P.cstride + l0;
 #pragma unroll
         for (int x = 0; x < R4; x++) {
             const int q = tid + x * NW * 64;                      // s = q / 32, 4-column chunk = q % 32
@@ -285,10 +397,10 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_mfma(SweepParams P) {
 
     // optional list of the non-zero tiles (see k_sweep): a block of this kernel spans NW*16 rows = NW/2 mask rows,
     // a tile half a mask bit
-    constexpr int MAXT = 4096;
+    constexpr int MAXT = LIST ? 4096 : 1;
     __shared__ unsigned short sTiles[MAXT];
     __shared__ int sNT, sPos;
-    const bool use_list = (NW * MT_ROWS) % 32 == 0 && (P.tile_mask != nullptr) && (ntiles <= MAXT);
+    const bool use_list = LIST && (NW * MT_ROWS) % 32 == 0 && (P.tile_mask != nullptr) && (ntiles <= MAXT);
     const int start_tile = (int)(((unsigned)blockIdx.x * (unsigned)P.skew) % (unsigned)ntiles);
     int nlist = ntiles;
     if (use_list) {
@@ -362,62 +474,21 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_mfma(SweepParams P) {
     for (int k = 0; k < 4; k++) sG[wave][g * 4 + k][r] = acc0[k] + acc1[k];
     __syncthreads();
 
-    if (SPLIT) {
-        for (int e = lane; e < MT_ROWS * S; e += 64) {
-            const int rr = e / S, s = e % S;
-            const int row = rbase + rr;
-            if (row < P.nrows) P.Gpart[((size_t)blockIdx.y * P.nrows + row) * S + s] = sG[wave][rr][s];
-        }
-        return;
-    }
-    for (int e = lane; e < MT_ROWS * S; e += 64) {
-        const int so = e / MT_ROWS, rr = e % MT_ROWS;      // consecutive lanes -> consecutive rows of one bin
-        const int row = rbase + rr;
-        if (row < P.nrows) {
-            const float* Mi = P.M + (size_t)P.mat[row] * S * S + so * S;
-            float v = 0.0f;
-            for (int s = 0; s < S; s++) v = fmaf(Mi[s], sG[wave][rr][s], v);
-            P.Rout[((size_t)P.rank * S + so) * P.rpr + row] = v;
-            float* b = P.B + (size_t)so * P.rpr + row;
-            *b = *b + v;
-        }
-    }
-}
-
-// sums the column-split partials in split order and applies M (one thread per row and output bin)
-template <int S>
-__global__ void k_sweep_epilogue(SweepParams P) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= P.nrows * S) return;
-    const int so = x / P.nrows, row = x % P.nrows;      // consecutive threads -> consecutive rows
-    float G[S];
-#pragma unroll
-    for (int s = 0; s < S; s++) G[s] = 0.0f;
-    for (int k = 0; k < P.ksplit; k++) {
-        const float* g = P.Gpart + ((size_t)k * P.nrows + row) * S;
-#pragma unroll
-        for (int s = 0; s < S; s++) G[s] += g[s];
-    }
-    const float* Mi = P.M + (size_t)P.mat[row] * S * S + so * S;
-    float v = 0.0f;
-#pragma unroll
-    for (int s = 0; s < S; s++) v = fmaf(Mi[s], G[s], v);
-    P.Rout[((size_t)P.rank * S + so) * P.rpr + row] = v;
-    float* b = P.B + (size_t)so * P.rpr + row;
-    *b = *b + v;
+    // the sweep_tail above reads P.S itself; rows of wave w are block rows w*16 ..
+    sweep_tail<NW * MT_ROWS, 16, NW * 64, SPLIT>(P, &sG[0][0][0], &sV[0][0], sD, &sFlag);
 }
 
 template <int S, int RR, int NW, int CPL, bool NT, int OCC = 1>
 static hipError_t launch_cfg(hipStream_t st, const SweepParams& p) {
     const int rows_per_block = RR * NW;
     dim3 grid((p.nrows + rows_per_block - 1) / rows_per_block, p.ksplit);
+    const bool list = p.tile_mask != nullptr;
     if (p.ksplit > 1) {
-        hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC, true>), grid, dim3(NW * 64), 0, st, p);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_sweep_epilogue<S>), dim3((p.nrows * S + 255) / 256), dim3(256), 0, st, p);
+        if (list) hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC, true, true>), grid, dim3(NW * 64), 0, st, p);
+        else hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC, true, false>), grid, dim3(NW * 64), 0, st, p);
     } else {
-        hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC, false>), grid, dim3(NW * 64), 0, st, p);
+        if (list) hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC, false, true>), grid, dim3(NW * 64), 0, st, p);
+        else hipLaunchKernelGGL((k_sweep<S, RR, NW, CPL, NT, OCC, false, false>), grid, dim3(NW * 64), 0, st, p);
     }
     return hipGetLastError();
 }
@@ -426,8 +497,20 @@ static hipError_t launch_cfg(hipStream_t st, const SweepParams& p) {
 // single pass is fastest; below that, cut columns until there are about 1024 blocks, each block
 // keeping at least 8 tiles (the ranges need not be equal).  Measured at N = 65 536 on one
 // MI355X (profiles/r01/sweep_shards.md): 8192 rows 0.437 ms unsplit -> 0.342 ms with 4 ranges.
+// rows per workgroup of the pass kernel launch_sweep picks: k_sweep: 4 waves x 8 rows; k_sweep_mfma: 4 x 16
+static int sweep_rows_per_block(int S) {
+    static int mfma = -1;
+    if (mfma < 0) { const char* e = getenv("DR_SWEEP_MFMA"); mfma = e ? atoi(e) : 1; }
+    if (S > 8 && mfma) return 4 * MT_ROWS;
+    return (S <= 8) ? 32 : 16;
+}
+int sweep_row_blocks(int nrows, int S) {
+    const int rpb = sweep_rows_per_block(S);
+    return (nrows + rpb - 1) / rpb;
+}
+
 int sweep_ksplit(int nrows, int S, int total_cols) {
-    const int rows_per_block = (S <= 8) ? 32 : 4 * MT_ROWS;      // k_sweep: 4 waves x 8 rows; k_sweep_mfma: 4 x 16
+    const int rows_per_block = sweep_rows_per_block(S);
     const int row_blocks = (nrows + rows_per_block - 1) / rows_per_block;
     const int ntiles = total_cols / 256;
     static int forced = -2;
@@ -447,32 +530,16 @@ static hipError_t launch_sweep_s(hipStream_t st, const SweepParams& p) {
     return launch_cfg<S, RR, 4, 1, true>(st, p);
 }
 
-static int sweep_cfg() {
-    static int cfg = -1;
-    if (cfg < 0) { const char* e = getenv("DR_SWEEP_CFG"); cfg = e ? atoi(e) : 0; }
-    return cfg;
-}
-
-template <int S>
-static void launch_epilogue_s(hipStream_t st, const SweepParams& p) {
-    hipLaunchKernelGGL((k_sweep_epilogue<S>), dim3((p.nrows * S + 255) / 256), dim3(256), 0, st, p);
-}
-
 static hipError_t launch_sweep_mfma(hipStream_t st, const SweepParams& p) {
     constexpr int NW = 4;
     dim3 grid((p.nrows + NW * MT_ROWS - 1) / (NW * MT_ROWS), p.ksplit);
+    const bool list = p.tile_mask != nullptr;
     if (p.ksplit > 1) {
-        hipLaunchKernelGGL((k_sweep_mfma<NW, true>), grid, dim3(NW * 64), 0, st, p);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        switch (p.S) {
-#define DR_EP(n) case n: launch_epilogue_s<n>(st, p); break;
-            DR_EP(9) DR_EP(10) DR_EP(11) DR_EP(12) DR_EP(13) DR_EP(14) DR_EP(15) DR_EP(16)
-#undef DR_EP
-            default: return hipErrorInvalidValue;
-        }
+        if (list) hipLaunchKernelGGL((k_sweep_mfma<NW, true, true>), grid, dim3(NW * 64), 0, st, p);
+        else hipLaunchKernelGGL((k_sweep_mfma<NW, true, false>), grid, dim3(NW * 64), 0, st, p);
     } else {
-        hipLaunchKernelGGL((k_sweep_mfma<NW, false>), grid, dim3(NW * 64), 0, st, p);
+        if (list) hipLaunchKernelGGL((k_sweep_mfma<NW, false, true>), grid, dim3(NW * 64), 0, st, p);
+        else hipLaunchKernelGGL((k_sweep_mfma<NW, false, false>), grid, dim3(NW * 64), 0, st, p);
     }
     return hipGetLastError();
 }
@@ -491,19 +558,6 @@ hipError_t launch_sweep(hipStream_t st, const SweepParams& p_in) {
     if (mfma < 0) { const char* e = getenv("DR_SWEEP_MFMA"); mfma = e ? atoi(e) : 1; }
     p.skew = skew;
     if (p.S > 8 && mfma) return launch_sweep_mfma(st, p);
-    if (p.rpr % 1024 == 0 && p.S == 8) {       // tuning variants (DR_SWEEP_CFG)
-        switch (sweep_cfg()) {
-            case 1: return launch_cfg<8, 8, 4, 1, false>(st, p);
-            case 2: return launch_cfg<8, 4, 8, 1, false>(st, p);
-            case 3: return launch_cfg<8, 4, 8, 2, false>(st, p);
-            case 4: return launch_cfg<8, 4, 4, 2, false>(st, p);
-            case 5: return launch_cfg<8, 2, 8, 4, false>(st, p);
-            case 6: return launch_cfg<8, 4, 8, 2, true>(st, p);
-            case 7: return launch_cfg<8, 4, 16, 1, false>(st, p);
-            case 8: return launch_cfg<8, 8, 8, 1, false>(st, p);
-            default: break;
-        }
-    }
     switch (p.S) {
 #define DR_CASE(n) case n: return launch_sweep_s<n>(st, p);
         DR_CASE(1) DR_CASE(2) DR_CASE(3) DR_CASE(4) DR_CASE(5) DR_CASE(6) DR_CASE(7) DR_CASE(8)
@@ -551,54 +605,52 @@ hipError_t launch_tile_mask(hipStream_t st, const float* F, int nrows, size_t ld
     return hipGetLastError();
 }
 
-// per-bin sums of the gathered residual (check_convergence, vs/Lightning.h:255-261), double
-__global__ void k_colsums(const float* __restrict__ R, int world, int S, int rpr, double* __restrict__ sums) {
+// per-bin sums of every chunk of a residual buffer into the chunk's own tail (after a reset; the passes keep the
+// tails themselves); check_convergence, vs/Lightning.h:255-261, in double
+__global__ void k_chunk_sums(float* __restrict__ R, int S, int rpr, size_t cstride) {
     __shared__ double sh[256];
-    const int s = blockIdx.x;
+    const int c = blockIdx.x, s = blockIdx.y;
+    float* chunk = R + (size_t)c * cstride;
+    const float* x = chunk + (size_t)s * rpr;
     double a = 0.0;
-    for (int c = 0; c < world; c++) {
-        const float* x = R + ((size_t)c * S + s) * rpr;
-        for (int i = threadIdx.x; i < rpr; i += 256) a += (double)x[i];
-    }
+    for (int i = threadIdx.x; i < rpr; i += 256) a += (double)x[i];
     sh[threadIdx.x] = a;
     __syncthreads();
     for (int w = 128; w >= 1; w >>= 1) {
         if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) sums[s] = sh[0];
+    if (threadIdx.x == 0) reinterpret_cast<double*>(chunk + (size_t)S * rpr)[s] = sh[0];
 }
 
-hipError_t launch_colsums(hipStream_t st, const float* R, int world, int S, int rpr, double* sums) {
-    hipLaunchKernelGGL(k_colsums, dim3(S), dim3(256), 0, st, R, world, S, rpr, sums);
+hipError_t launch_chunk_sums(hipStream_t st, float* R, int world, int S, int rpr, size_t cstride) {
+    hipLaunchKernelGGL(k_chunk_sums, dim3(world, S), dim3(256), 0, st, R, S, rpr, cstride);
     return hipGetLastError();
 }
 
-__global__ void k_scatter_rows(const float* __restrict__ src, int N, int S, int rpr, float* __restrict__ dst) {
+__global__ void k_scatter_rows(const float* __restrict__ src, int N, int S, int rpr, size_t cstride, float* __restrict__ dst) {
     size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= (size_t)N * S) return;
     int s = (int)(x / N), i = (int)(x % N);
     int c = i / rpr, l = i % rpr;
-    dst[((size_t)c * S + s) * rpr + l] = src[(size_t)i * S + s];
+    dst[(size_t)c * cstride + (size_t)s * rpr + l] = src[(size_t)i * S + s];
 }
-__global__ void k_gather_rows(const float* __restrict__ src, int N, int S, int rpr, float* __restrict__ dst) {
+__global__ void k_gather_rows(const float* __restrict__ src, int N, int S, int rpr, size_t cstride, float* __restrict__ dst) {
     size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= (size_t)N * S) return;
     int s = (int)(x / N), i = (int)(x % N);
     int c = i / rpr, l = i % rpr;
-    dst[(size_t)i * S + s] = src[((size_t)c * S + s) * rpr + l];
+    dst[(size_t)i * S + s] = src[(size_t)c * cstride + (size_t)s * rpr + l];
 }
 
-hipError_t launch_scatter_rows(hipStream_t st, const float* src, int N, int S, int rpr, int world, float* dst) {
-    (void)world;
+hipError_t launch_scatter_rows(hipStream_t st, const float* src, int N, int S, int rpr, size_t cstride, float* dst) {
     size_t n = (size_t)N * S;
-    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, N, S, rpr, dst);
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, N, S, rpr, cstride, dst);
     return hipGetLastError();
 }
-hipError_t launch_gather_rows(hipStream_t st, const float* src, int N, int S, int rpr, int world, float* dst) {
-    (void)world;
+hipError_t launch_gather_rows(hipStream_t st, const float* src, int N, int S, int rpr, size_t cstride, float* dst) {
     size_t n = (size_t)N * S;
-    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, N, S, rpr, dst);
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, N, S, rpr, cstride, dst);
     return hipGetLastError();
 }
 

@@ -2,10 +2,13 @@
  * daisyriot_hip.h -- C ABI of libdaisyriot_hip.so: DaisyRiot's radiosity hot
  * path (form-factor assembly + per-bin light-pass iteration) on one MI355X.
  *
- * One context drives one GPU (one process per GPU).  Row-sharded multi-GPU
- * runs create one context per rank, all with the same mesh, and call
- * dr_set_shard + dr_comm_init; the only data-path collective is the
- * all-gather of the residual vector after each pass.
+ * One context drives one GPU.  Row-sharded multi-GPU runs are either one
+ * process per GPU -- one context per rank, all with the same mesh,
+ * dr_set_shard + dr_comm_init -- or one process for all GPUs: a dr_group
+ * (dr_group_create(device_ids, n, ..)), whose calls run on all its devices at
+ * once.  The only data-path collective of a pass is the all-gather of the
+ * residual vector (with each rank's convergence sums riding in the same
+ * message); the assembly adds one all-to-all of ray counts.
  *
  * Each entry point names the reference interface it replaces ("vs/" =
  * "visual studio/" in asylunatic/DaisyRiot).  No C++ or torch types cross
@@ -73,7 +76,11 @@ int dr_get_shard(dr_context* ctx, int* row0, int* nrows, int* rows_per_rank);
  * rank `rank` of `world` owns for N patches, and where element (patch i, bin s) of the
  * residual lives in the gathered device buffer [world][S][rows_per_rank]. */
 int dr_shard_rows(int N, int rank, int world, int* row0, int* nrows, int* rows_per_rank);
+/* A gathered residual buffer is [world][dr_residual_chunk_floats]: per rank S*rows_per_rank values, bin-major,
+ * followed by the chunk's per-bin sums (DR_MAX_BINS doubles = 2*DR_MAX_BINS floats; check_convergence,
+ * vs/Lightning.h:255-261) -- the convergence scalars travel in the same all-gather as the residual. */
 size_t dr_residual_offset(int i, int s, int S, int rows_per_rank);
+size_t dr_residual_chunk_floats(int S, int rows_per_rank);
 
 /* ---- scene --------------------------------------------------------------------- */
 /* Exactly the MeshS / SimpleMesh arrays (vs/MeshS.h:14-20, vs/Defines.h:14-23;
@@ -99,18 +106,23 @@ int dr_formfactors_assemble(dr_context* ctx, const float* uv, int K,
 
 /* Multi-rank assembly (no reference counterpart: the reference is single-GPU).  A pair of patches in
  * two ranks' rows is needed by both (F[i][j] and F[j][i] share the ray count); with an RCCL
- * communicator dr_formfactors_assemble traces it on one of the two ranks only and all-gathers the
- * 64 x 64-byte ray-count slots of the tile pairs.  Without one (DR_NO_COMM timing runs, a single rank of a
- * shard on its own) every rank traces all pairs that touch its rows.  A host that moves buffers itself
- * does the same in steps: ..._split on every rank, then every rank's export chunk
- * (dr_vis_exchange_bytes bytes) imported into every other rank, then ..._finish on every rank. */
+ * communicator dr_formfactors_assemble traces it on one of the two ranks only and sends the
+ * 64 x 64-byte ray-count slots of the tile pairs to the other (one all-to-all: a rank receives
+ * (world-1) blocks of (rows_per_rank/64)^2 slots, about N*N/world bytes, not N*N).  Without one
+ * (DR_NO_COMM timing runs, a single rank of a shard on its own) every rank traces all pairs that touch
+ * its rows.  A host that moves buffers itself does the same in steps: ..._split on every rank, then
+ * for every ordered pair of ranks (a, b) the block a exports for b (dr_vis_exchange_bytes bytes)
+ * imported into b as coming from a, then ..._finish on every rank. */
 /* pure host arithmetic: the rank that traces the pair of patches (a, b) in a `world`-way assembly (-1: bad argument) */
 int dr_vis_exchange_tracer(int N, int world, int patch_a, int patch_b);
+/* pure host arithmetic: does a world-way assembly take the exchange path on cards of device_bytes (slot buffers +
+ * F shard + optional ray counts within 85 % of it)?  Deliberately no rank argument: every rank must decide alike. */
+int dr_vis_exchange_fits(int N, int world, int keep_visibility, size_t device_bytes);
 int dr_formfactors_assemble_split(dr_context* ctx, const float* uv, int K,
                                   float origin_eps, int rule, int keep_visibility);
-int dr_vis_exchange_bytes(dr_context* ctx, size_t* chunk_bytes);
-int dr_vis_exchange_export(dr_context* ctx, void* chunk_out);
-int dr_vis_exchange_import(dr_context* ctx, int src_rank, const void* chunk_in);
+int dr_vis_exchange_bytes(dr_context* ctx, size_t* block_bytes);
+int dr_vis_exchange_export(dr_context* ctx, int dst_rank, void* block_out, size_t bytes);
+int dr_vis_exchange_import(dr_context* ctx, int src_rank, const void* block_in, size_t bytes);
 int dr_formfactors_assemble_finish(dr_context* ctx);
 
 /* Unoccluded integrand only (parallellism::calculateRow, vs/parallellism.cu:91-111):
@@ -140,9 +152,14 @@ int dr_solver_step(dr_context* ctx, int n_passes, float* residual_sum_out);
 /* converge_lightning (vs/Lightning.h:145-151: total sum > threshold;
  * per_bin != 0 = the RGB rule :336-340, any bin sum > threshold).  Stops after
  * max_iters passes at the latest (the reference has no cap and BW never
- * terminates in closed scenes). */
+ * terminates in closed scenes).  The test runs on the device at the head of
+ * every pass (from the sums the previous pass left in the residual's tails);
+ * the host queues passes in batches and looks at the result once per batch
+ * (dr_solver_set_check_interval, default 8): passes queued behind the
+ * converged one do nothing, iters_out counts the real ones. */
 int dr_solver_converge(dr_context* ctx, float threshold, int per_bin,
                        int max_iters, int* iters_out);
+int dr_solver_set_check_interval(dr_context* ctx, int passes);
 /* reset() (vs/Lightning.h:159-165): R = B = E */
 int dr_solver_reset(dr_context* ctx);
 /* B (lightningvalues) and R (residualvector), N*S patch-major, either nullable.
@@ -175,21 +192,45 @@ int dr_display_vertex_colors(dr_context* ctx, const float* rgb_all, const int32_
 /* 128-byte RCCL unique id made on rank 0 and handed to every rank by the host. */
 int dr_comm_unique_id(void* out128);
 int dr_comm_init(dr_context* ctx, const void* id128, int rank, int world);
+/* what the context's RCCL communicator itself reports (ncclCommUserRank / ncclCommCount); -1 / 0 without one */
+int dr_comm_info(dr_context* ctx, int* rccl_rank, int* rccl_world);
 /* Host-staged exchange for hosts without RCCL (MPI staging, tests): after dr_comm_manual the
  * passes run without a collective and the host moves the residual chunks itself after EVERY
- * dr_solver_step(ctx, 1, ..): export this rank's new chunk (S*rows_per_rank floats, bin-major),
+ * dr_solver_step(ctx, 1, ..): export this rank's new chunk (dr_residual_chunk_floats floats),
  * import every other rank's chunk. */
 int dr_comm_manual(dr_context* ctx);
 int dr_exchange_export(dr_context* ctx, float* chunk_out);
-int dr_exchange_import(dr_context* ctx, int src_rank, const float* chunk_in);
+int dr_exchange_import(dr_context* ctx, int src_rank, const float* chunk_in, size_t n_floats);
+
+/* ---- one process, several GPUs (the reference is one process: main.cpp:55-154, Lightning.h:446-457) ---- */
+/* n contexts, rank r on device_ids[r], rows of F sharded over them; every call below runs on all devices at once
+ * (asynchronous launches on one stream per device, one wait at the end).  Distinct devices exchange through RCCL
+ * (ncclCommInitAll, grouped calls); the same device listed several times -- a rehearsal of the group on one GPU --
+ * or DR_GROUP_EXCHANGE=p2p uses peer copies (hipMemcpyPeerAsync) instead. */
+typedef struct dr_group dr_group;
+int dr_group_create(const int* device_ids, int n_devices, dr_group** out);
+int dr_group_destroy(dr_group* g);
+int dr_group_info(dr_group* g, int* n_devices, int* uses_rccl);
+/* rank r's context, owned by the group: for reads, dr_get_info, dr_profile_enable, display colours */
+int dr_group_context(dr_group* g, int rank, dr_context** out);
+int dr_group_set_mesh(dr_group* g, const float* vertices, int V, const float* normals, int Nn,
+                      const int32_t* tri_vertex_idx, const int32_t* tri_normal_idx, int N);
+int dr_group_assemble(dr_group* g, const float* uv, int K, float origin_eps, int rule, int keep_visibility);
+int dr_group_solver_init(dr_group* g, int S, const float* E, const float* M, int n_mat, const int32_t* mat_of_patch);
+int dr_group_solver_step(dr_group* g, int n_passes, float* residual_sum_out);
+int dr_group_solver_converge(dr_group* g, float threshold, int per_bin, int max_iters, int* iters_out);
+int dr_group_solver_reset(dr_group* g);
+/* B: all N*S values (every rank writes its rows); R: the gathered residual */
+int dr_group_solver_read(dr_group* g, float* B, float* R);
+int dr_group_synchronize(dr_group* g);
 
 /* ---- measurement ----------------------------------------------------------------- */
 typedef struct {
     int    N, S, rank, world, row0, nrows, rows_per_rank, n_bvh_nodes;
     size_t ld_F;              /* leading dimension of F in floats */
     size_t bytes_F;           /* resident bytes of the F shard */
-    double last_assemble_ms;  /* hipEvent time of the last assemble (BVH + tiles) */
-    double last_bvh_ms;
+    double last_assemble_ms;  /* hipEvent time of the tile kernel(s) of the last assemble (the BVH build is last_bvh_ms) */
+    double last_bvh_ms;       /* hipEvent time of the LBVH build in dr_scene_set_mesh */
     uint64_t pairs_traced;    /* unordered pairs traced by the last assemble */
     uint64_t sweep_launches;  /* profiled sweep launches since dr_profile_reset */
     double sweep_ms_total;    /* their summed hipEvent durations */

@@ -44,10 +44,33 @@ def test_shard_arithmetic():
     assert api.shard_rows(65536, 3, 8) == (24576, 8192, 8192)
     with pytest.raises(api.DaisyRiotError):
         api.shard_rows(10, 2, 2)
-    # residual layout: chunk-major, bin-major inside a chunk
+    # residual layout: chunk-major, bin-major inside a chunk, every chunk followed by its per-bin sums (16 doubles)
+    chunk = api.residual_chunk_floats(8, 256)
+    assert chunk == 8 * 256 + 32
     assert api.residual_offset(0, 0, 8, 256) == 0
     assert api.residual_offset(5, 2, 8, 256) == 2 * 256 + 5
-    assert api.residual_offset(300, 2, 8, 256) == (1 * 8 + 2) * 256 + 44
+    assert api.residual_offset(300, 2, 8, 256) == chunk + 2 * 256 + 44
+
+
+def test_exchange_decision_is_rank_independent():
+    """whether a multi-rank assembly exchanges ray counts is decided from N, world and the card size alone -- a rank that
+    decided from its own (shorter, last) shard would strand the others in the collective (round-1 advisor finding)"""
+    import inspect
+    assert "rank" not in inspect.signature(api.vis_exchange_fits).parameters
+    card = 288 * 2 ** 30
+    # small problems exchange, problems whose F shard alone fills the card do not; the answer flips exactly once in N
+    assert api.vis_exchange_fits(65536, 8, False, card) and api.vis_exchange_fits(262144, 8, False, card)
+    assert not api.vis_exchange_fits(700000, 8, False, card)
+    prev = True
+    for N in range(500000, 600000, 1024):
+        cur = api.vis_exchange_fits(N, 8, True, card)
+        assert not (cur and not prev)
+        prev = cur
+    assert not prev
+    # the bytes counted: two slot buffers of world*(rpr/64)^2*4096 + the F shard (rpr x world*rpr floats)
+    rpr = api.shard_rows(65536, 0, 8)[2]
+    need = 2 * 8 * (rpr // 64) ** 2 * 4096 + 4 * rpr * 8 * rpr
+    assert api.vis_exchange_fits(65536, 8, False, int(need / 0.85) + 4096) and not api.vis_exchange_fits(65536, 8, False, int(need / 0.85) - 4096)
 
 
 def test_errors_without_a_gpu_are_reported_not_swallowed():

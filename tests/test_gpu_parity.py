@@ -170,6 +170,19 @@ def test_converge_stops_at_the_same_pass(uv50):
         assert it_cap == 7
         c.reset()
         assert c.converge(200.0, per_bin=False, max_iters=50) == ob.converge(F, sc.M, sc.mat_of_patch, E, 200.0, False, 50)[0]
+        # the convergence test runs on the device; the host looks once per batch of queued passes: whatever the batch,
+        # the same pass count and the same state (passes queued behind the converged one do nothing)
+        for every in (1, 3, 64):
+            c.set_check_interval(every)
+            c.reset()
+            assert c.converge(1e-4, per_bin=True, max_iters=500) == it_rgb
+            Bk, Rk = c.read()
+            assert np.array_equal(_bits(Bk), _bits(Bg))
+            assert abs(c.residual_sums().sum() - Rk.astype(np.float64).sum()) <= 1e-9 * max(1.0, Rk.sum())
+            c.step(1)                                                    # and the state is consistent: stepping on works
+            c.reset()
+            assert c.converge(0.0, per_bin=False, max_iters=7) == 7
+        c.set_check_interval(8)
 
 
 def test_sweep_on_loaded_rows_and_padding():
@@ -555,7 +568,7 @@ def test_c5_shard_256k_fluorescent(uv50):
         Bo = E[r:r + 48].copy()
         Ro = ob.sweep_rows(Fs, sc.M, sc.mat_of_patch, E, Bo, row0=r)
         assert (np.abs(B1[r:r + 48] - Bo) / (np.abs(Bo).max(axis=0) + 1e-30)).max() < 2e-5
-        own = c.exchange_export().reshape(8, rpr)           # this rank's new residual chunk, bin-major
+        own = c.exchange_export()[:8 * rpr].reshape(8, rpr)           # this rank's new residual chunk, bin-major (+ its sums)
         assert (np.abs(own[:, 30000:30048].T - Ro) / (np.abs(Ro).max(axis=0) + 1e-30)).max() < 2e-5
 
 
@@ -579,11 +592,12 @@ def test_multi_rank_assembly_with_ray_count_exchange(world, n, rule, uv50):
         ranks.append(c)
     total = sum(c.info().pairs_traced for c in ranks)
     assert total == traced_once                                    # nothing traced twice, nothing left out
-    chunks = [c.vis_exchange_export() for c in ranks]
+    # the all-to-all: the block rank a traced for rank b goes to b (and only to b)
+    blocks = {(a, b): ranks[a].vis_exchange_export(b) for a in range(world) for b in range(world) if a != b}
     for d, c in enumerate(ranks):
-        for s_, ch in enumerate(chunks):
+        for s_ in range(world):
             if s_ != d:
-                c.vis_exchange_import(s_, ch)
+                c.vis_exchange_import(s_, blocks[(s_, d)])
         c.assemble_finish()
     for c in ranks:
         row0, nrows, _ = c.shard()
@@ -673,3 +687,73 @@ def test_work_on_the_callers_stream(uv50):
         c.step(1)
         B1, R1 = c.read()
     assert np.array_equal(_bits(B1), _bits(B0)) and np.array_equal(_bits(R1), _bits(R0))
+
+
+@pytest.mark.parametrize("world,S,n", [(2, 8, 700), (3, 3, 2500), (4, 9, 1300)])
+def test_group_one_process_several_ranks(world, S, n, uv50):
+    """dr_group: one process, `world` ranks (here all on GPU 0: the one-GPU rehearsal, exchange by peer copies) -- assembly
+    with ray-count exchange, passes and converge give the single-context results"""
+    sc = scenes.cornell_box(n, S=S, fluorescent=(S >= 8))
+    E = sc.emission(7.0)
+    with _ctx(sc) as c:
+        c.assemble(uv50, keep_visibility=True)
+        F, V = c.read_rows(0, sc.N), c.read_visibility(0, sc.N)
+        traced_once = c.info().pairs_traced
+        c.solver_init(E, sc.M, sc.mat_of_patch)
+        c.step(4)
+        B1, R1 = c.read()
+        c.reset()
+        thr, per_bin = (1e-3, True) if S == 3 else (0.5, False)
+        it1 = c.converge(thr, per_bin=per_bin, max_iters=300)
+        Bc1, _ = c.read()
+    with api.Group([0] * world) as g:
+        assert not g.uses_rccl()
+        g.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+        g.assemble(uv50, keep_visibility=True)
+        assert sum(c.info().pairs_traced for c in g.ranks) == traced_once
+        for c in g.ranks:
+            row0, nrows, _ = c.shard()
+            if nrows:
+                assert np.array_equal(c.read_visibility(row0, nrows), V[row0:row0 + nrows])
+                assert np.array_equal(_bits(c.read_rows(row0, nrows)), _bits(F[row0:row0 + nrows]))
+        g.solver_init(E, sc.M, sc.mat_of_patch)
+        tot = g.step(4, want_sum=True)
+        B, R = g.read()
+        assert np.allclose(B, B1, rtol=2e-6, atol=1e-12) and np.allclose(R, R1, rtol=2e-6, atol=1e-12)
+        assert abs(tot - R1.astype(np.float64).sum()) <= 1e-5 * max(1.0, abs(tot))
+        for c in g.ranks:                                     # every rank holds the same gathered residual
+            _, Rc = c.read(B=False)
+            assert np.array_equal(_bits(Rc), _bits(R))
+        g.reset()
+        assert g.converge(thr, per_bin=per_bin, max_iters=300) == it1
+        Bc, _ = g.read()
+        assert np.allclose(Bc, Bc1, rtol=2e-6, atol=1e-12)
+
+
+def test_shaft_list_option_is_exact(uv50, monkeypatch):
+    """DR_SHAFT=1 (tile-pair shaft culling, off by default): same ray counts and F as the brute-force oracle on a soup far from
+    the origin, on the Cornell box, and with an origin offset that throws rays out of their tile's box (walks from the root)"""
+    monkeypatch.setenv("DR_SHAFT", "1")
+    for mn in ("8", "128"):
+        monkeypatch.setenv("DR_SHAFT_MIN", mn)
+        rs = np.random.RandomState(5)
+        n = 300
+        c0 = rs.random_sample((n, 1, 3)) * 2 - 1
+        tri = (c0 + (rs.random_sample((n, 3, 3)) - 0.5) * 0.4) * 3.0 + 250.0
+        v = tri.reshape(-1, 3).astype(np.float32)
+        tv = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+        nrm = rs.normal(size=(16, 3)).astype(np.float32)
+        tn = rs.randint(0, 16, size=(n, 3)).astype(np.int32)
+        for eps in (api.ORIGIN_EPS, 0.3):
+            with api.Context(0) as c:
+                c.set_mesh(v, nrm, tv, tn)
+                c.assemble(uv50, eps=eps, keep_visibility=True)
+                vis, F = c.read_visibility(0, n), c.read_rows(0, n)
+            Fo, viso, _ = ob.assemble_rows(ob.Mesh(v, nrm, tv, tn), uv50, eps=eps, bvh=False)
+            assert np.array_equal(vis, viso) and np.array_equal(_bits(F), _bits(Fo))
+        sc = scenes.cornell_box(1500, S=3)
+        with _ctx(sc) as c:
+            c.assemble(uv50, keep_visibility=True)
+            vis, F = c.read_visibility(0, sc.N), c.read_rows(0, sc.N)
+        Fo, viso, _ = ob.assemble_rows(ob.Mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n), uv50, bvh=True)
+        assert np.array_equal(vis, viso) and np.array_equal(_bits(F), _bits(Fo))

@@ -35,22 +35,29 @@ def _rank_main(rank, world, port, N, S, passes, out_dir):
     # each rank assembles only its own rows (no communication in the assembly)
     F, _, _ = ob.assemble_rows(m, uv, row0=row0, nrows=nrows, bvh=True, want_vis=False)
     E = sc.emission(7.0)
-    # gathered residual in the device layout [world][S][rpr]
-    full = np.zeros(world * S * rpr, np.float32)
+    # gathered residual in the device layout [world][chunk]: a chunk = [S][rpr] + the chunk's per-bin sums (16 doubles)
+    cf = api.residual_chunk_floats(S, rpr)
+    full = np.zeros(world * cf, np.float32)
     idx = np.array([[api.residual_offset(i, s, S, rpr) for s in range(S)] for i in range(sc.N)])
     full[idx] = E
     B = E[row0:row0 + nrows].copy()
+    sums_seen = []
     for _ in range(passes):
         Rin = full[idx]                                       # N x S view of the gathered buffer
         Rout = ob.sweep_rows(F, sc.M, sc.mat_of_patch, Rin, B, row0=row0)
-        chunk = np.zeros(S * rpr, np.float32)                 # own chunk, bin-major, zero padded
+        chunk = np.zeros(cf, np.float32)                      # own chunk, bin-major, zero padded
         for s in range(S):
             chunk[s * rpr:s * rpr + nrows] = Rout[:, s]
-        gathered = torch.zeros(world * S * rpr)
+        # the rank's share of the convergence sums rides in the same message (no second collective)
+        chunk[S * rpr:].view(np.float64)[:S] = Rout.astype(np.float64).sum(axis=0)
+        gathered = torch.zeros(world * cf)
         dist.all_gather_into_tensor(gathered, torch.from_numpy(chunk))
         full = gathered.numpy().copy()
+        tails = full.reshape(world, cf)[:, S * rpr:].copy().view(np.float64)[:, :S]
+        sums_seen.append(tails.sum(axis=0))
     np.save(os.path.join(out_dir, "B_%d.npy" % rank), B)
     np.save(os.path.join(out_dir, "R_%d.npy" % rank), full[idx])
+    np.save(os.path.join(out_dir, "sums_%d.npy" % rank), np.array(sums_seen))
     dist.destroy_process_group()
 
 
@@ -63,9 +70,15 @@ def test_row_sharded_passes_equal_unsharded(world, tmp_path):
     F, _, _ = ob.assemble_rows(m, scenes.visibility_samples(50), bvh=True, want_vis=False)
     E = sc.emission(7.0)
     R, B = E.copy(), E.copy()
+    sums = []
     for _ in range(passes):
         R = ob.sweep_rows(F, sc.M, sc.mat_of_patch, R, B)
+        sums.append(R.astype(np.float64).sum(axis=0))
     Bs = []
+    for r in range(world):          # every rank saw the same per-bin sums after every pass: they all stop at the same pass
+        got = np.load(tmp_path / ("sums_%d.npy" % r))
+        assert np.array_equal(got, np.load(tmp_path / "sums_0.npy"))
+        assert np.allclose(got, np.array(sums), rtol=1e-12)
     for r in range(world):
         row0, nrows, _ = api.shard_rows(N, r, world)
         Br = np.load(tmp_path / ("B_%d.npy" % r))
@@ -77,9 +90,10 @@ def test_row_sharded_passes_equal_unsharded(world, tmp_path):
 
 
 def _assembly_rank_main(rank, world, port, N, out_dir):
-    """the ray-count exchange of a multi-rank assembly over a real collective: every tile pair between two ranks' rows
+    """the ray-count exchange of a multi-rank assembly over real messages: every tile pair between two ranks' rows
     is 'traced' (here: taken from the oracle) by the rank dr_vis_exchange_tracer names, its 64 x 64 counts go to slot
-    (own tile, foreign tile) of the rank's chunk, one all-gather, and the other rank picks slot (foreign, own)"""
+    [other rank][own tile][foreign tile] of the rank's send blocks, block p travels to rank p only (all-to-all), and the
+    other rank picks slot [tracer rank][foreign tile][own tile] of what it received"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -98,7 +112,7 @@ def _assembly_rank_main(rank, world, port, N, out_dir):
         blk[:sub.shape[0], :sub.shape[1]] = sub
         return blk if o < t else blk.T
 
-    chunk = np.full((T, nT, 64, 64), 255, np.uint8)
+    send = np.full((world, T, T, 64, 64), 255, np.uint8)
     own_tiles = range(row0 // 64, (row0 + nrows + 63) // 64)
     traced = 0
     for o in own_tiles:
@@ -106,17 +120,26 @@ def _assembly_rank_main(rank, world, port, N, out_dir):
             if t // T == rank:
                 continue
             if api.vis_exchange_tracer(sc.N, world, o * 64, t * 64) == rank:
-                chunk[o - rank * T, t] = tile(Vown, o, t)
+                send[t // T, o - rank * T, t % T] = tile(Vown, o, t)
                 traced += 1
-    gathered = torch.zeros(world * chunk.size, dtype=torch.uint8)
-    dist.all_gather_into_tensor(gathered, torch.from_numpy(chunk.reshape(-1)))
-    G = gathered.numpy().reshape(world * T, nT, 64, 64)
+    recv = np.full((world, T, T, 64, 64), 255, np.uint8)
+    reqs, bufs = [], {}
+    for p in range(world):
+        if p == rank:
+            continue
+        bufs[p] = torch.zeros(send[p].size, dtype=torch.uint8)
+        reqs.append(dist.irecv(bufs[p], src=p))
+        reqs.append(dist.isend(torch.from_numpy(send[p].reshape(-1).copy()), dst=p))
+    for q in reqs:
+        q.wait()
+    for p, b in bufs.items():
+        recv[p] = b.numpy().reshape(T, T, 64, 64)
     # rebuild the counts of the own rows: own x own and own-traced pairs locally, the rest from the slots
     V = np.full((nrows, sc.N), 255, np.uint8)
     for o in own_tiles:
         for t in range(nT):
             mine = (t // T == rank) or api.vis_exchange_tracer(sc.N, world, o * 64, t * 64) == rank
-            blk = tile(Vown, o, t) if mine else G[t, o]
+            blk = tile(Vown, o, t) if mine else recv[t // T, t % T, o - rank * T]
             blk = blk if o < t else blk.T       # back to rows = this rank's tile
             r0, c0 = o * 64 - row0, t * 64
             h, w = min(64, nrows - r0), min(64, sc.N - c0)
