@@ -92,6 +92,7 @@ struct dr_context {
     double* d_blk_sums = nullptr;
     int* d_ctl = nullptr;             // [0] passes done, [1] a pass found the residual converged (SweepParams::ctl)
     int check_every = 8;              // dr_solver_converge looks at d_ctl once per this many queued passes
+    bool tails_valid = false;         // the current residual's chunk tails hold its per-bin sums
     // optional zero-block skipping of the light pass (dr_solver_skip_zero_blocks)
     bool skip_zero = false, mask_valid = false;
     unsigned* d_mask = nullptr;
@@ -212,6 +213,13 @@ int sweep_once(dr_context* c, int conv_mode = 0, float thr = 0.0f) {
     p.B = c->d_B; p.M = c->d_M; p.mat = c->d_mat; p.n_mat = c->n_mat;
     p.skew = 0; p.ksplit = c->ksplit; p.Gpart = c->d_Gpart;
     p.tickets = c->d_tickets; p.blk_sums = c->d_blk_sums; p.ctl = c->d_ctl; p.conv_mode = conv_mode; p.conv_thr = thr;
+    // plain passes (dr_solver_step) do not form the sums; whoever asks for them afterwards gets them from k_chunk_sums
+    p.want_sums = conv_mode != 0 ? 1 : 0;
+    if (conv_mode != 0 && !c->tails_valid) {
+        HIPCHK(launch_chunk_sums(c->stream, c->d_R[c->cur], c->world, c->S, c->rpr, c->cstride));
+        c->tails_valid = true;
+    }
+    if (conv_mode == 0) c->tails_valid = false;
     p.tile_mask = nullptr; p.mask_words = 0;
     if (c->skip_zero) {
         if (!c->mask_valid) { int rc = build_tile_mask(c); if (rc) return rc; }
@@ -246,6 +254,10 @@ int sweep_once(dr_context* c, int conv_mode = 0, float thr = 0.0f) {
 
 // per-bin sums of the current residual: the chunks' tails (kept by the passes themselves), added up chunk by chunk
 int read_sums(dr_context* c, double* sums) {
+    if (!c->tails_valid) {
+        HIPCHK(launch_chunk_sums(c->stream, c->d_R[c->cur], c->world, c->S, c->rpr, c->cstride));
+        c->tails_valid = true;
+    }
     std::vector<double> tails((size_t)c->world * MAX_BINS);
     HIPCHK(hipMemcpy2DAsync(tails.data(), sizeof(double) * MAX_BINS, c->d_R[c->cur] + (size_t)c->S * c->rpr, sizeof(float) * c->cstride,
                             sizeof(double) * MAX_BINS, (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
@@ -722,6 +734,7 @@ int dr_solver_reset(dr_context* c) {
     const size_t full = (size_t)c->world * c->cstride;
     c->cur = 0;
     HIPCHK(hipMemcpyAsync(c->d_R[0], c->d_E, sizeof(float) * full, hipMemcpyDeviceToDevice, c->stream));
+    c->tails_valid = true;            // d_E carries its sums (dr_solver_init)
     HIPCHK(hipMemcpyAsync(c->d_B, c->d_E + (size_t)c->rank * c->cstride, sizeof(float) * (size_t)c->S * c->rpr,
                           hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -924,6 +937,7 @@ int dr_exchange_import(dr_context* c, int src_rank, const float* in, size_t n_fl
     if (!in || src_rank < 0 || src_rank >= c->world) return fail(DR_ERR_INVALID, "bad source rank %d", src_rank);
     const size_t n = c->cstride;
     if (n_floats != n) return fail(DR_ERR_INVALID, "a residual chunk is %zu floats (dr_residual_chunk_floats), got %zu", n, n_floats);
+    c->tails_valid = false;           // a host-staged chunk carries whatever tail its exporter had
     HIPCHK(hipMemcpyAsync(c->d_R[c->cur] + (size_t)src_rank * n, in, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return DR_OK;

@@ -125,6 +125,7 @@ struct SweepParams {
     int conv_mode;
     float conv_thr;
     int* ctl;
+    int want_sums;        // form the new residual's per-bin sums and leave them in the chunk's tail (always with conv_mode != 0)
     // optional: one bit per block of 32 rows x 256 columns of F, set where the block holds a non-zero; blocks whose
     // bit is clear are not read (null = read everything).  mask_words = 32-bit words per row block.
     const unsigned* tile_mask;

@@ -39,28 +39,30 @@ __device__ __forceinline__ bool residual_converged(const SweepParams& P) {
     return P.conv_mode == 2 ? !any : !(tot > (double)P.conv_thr);
 }
 
+// Hand-off between the blocks of one launch without fences (MI355X_MICROARCH.md, "Workgroup dispatch ... inter-workgroup
+// visibility", the table of hand-offs with sc1 loads in place of the acquire, first row): every byte that another block
+// will read is stored write-through (relaxed agent-scope store = global_store ... sc1) and read with sc1 loads
+// (relaxed agent-scope load: served past the CU's L1); each storing wave waits for its stores (vmcnt(0)), then ONE lane
+// of the block adds to the counter; the block whose add returns the last ticket reads after a workgroup barrier.  An
+// agent-scope release/acquire pair per block (buffer_wbl2 + buffer_inv) cost 4 % of the whole pass at 2048 blocks.
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // one arrival at a counter that `expected` blocks arrive at; true for the block that arrives last (it also rearms the
-// counter for the next pass).  Everything the block wrote before is visible to whoever sees its arrival (agent-scope
-// release before, acquire after: MI355X_MICROARCH.md, "Workgroup dispatch ... inter-workgroup visibility").
+// counter for the next pass)
 __device__ __forceinline__ bool arrive_last(unsigned* counter, unsigned expected, int* sFlag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have left
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned t = atomicAdd(counter, 1u);
         const bool last = (t == expected - 1u);
         if (last) atomicExch(counter, 0u);      // through the same path as the adds
         *sFlag = last ? 1 : 0;
     }
     __syncthreads();
-    const bool last = *sFlag != 0;
-    if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    return last;
+    return *sFlag != 0;
 }
 
 // What follows the stream over F in both pass kernels.  sGf[ROWSB][SPAD] (LDS) holds the block's rows' sums F*R over
@@ -79,7 +81,7 @@ __device__ __forceinline__ void sweep_tail(const SweepParams& P, float* sGf, flo
         for (int e = tid; e < ROWSB * S; e += NT) {
             const int rl = e / S, s2 = e % S;
             const int row = row0b + rl;
-            if (row < P.nrows) P.Gpart[((size_t)blockIdx.y * P.nrows + row) * S + s2] = sGf[rl * SPAD + s2];
+            if (row < P.nrows) st_agent(&P.Gpart[((size_t)blockIdx.y * P.nrows + row) * S + s2], sGf[rl * SPAD + s2]);
         }
         if (!arrive_last(&P.tickets[1 + blockIdx.x], gridDim.y, sFlag)) return;
         for (int e = tid; e < ROWSB * S; e += NT) {
@@ -87,7 +89,7 @@ __device__ __forceinline__ void sweep_tail(const SweepParams& P, float* sGf, flo
             const int row = row0b + rl;
             float g = 0.0f;
             if (row < P.nrows)
-                for (int k = 0; k < (int)gridDim.y; k++) g += P.Gpart[((size_t)k * P.nrows + row) * S + s2];
+                for (int k = 0; k < (int)gridDim.y; k++) g += ld_agent(&P.Gpart[((size_t)k * P.nrows + row) * S + s2]);
             sGf[rl * SPAD + s2] = g;
         }
         __syncthreads();
@@ -105,18 +107,21 @@ __device__ __forceinline__ void sweep_tail(const SweepParams& P, float* sGf, flo
         }
         sV[so * ROWSB + rl] = v;
     }
+    // the per-bin sums of the new residual are only formed for passes that ask for them (dr_solver_converge): the
+    // hand-off below holds every block for a few microseconds, about 1 % of a 64k-row pass
+    if (!P.want_sums) return;
     __syncthreads();
     if (tid < S) {
         double a = 0.0;
         for (int rl = 0; rl < ROWSB; rl++) a += (double)sV[tid * ROWSB + rl];
-        P.blk_sums[(size_t)blockIdx.x * S + tid] = a;
+        st_agent(&P.blk_sums[(size_t)blockIdx.x * S + tid], a);
     }
     if (!arrive_last(&P.tickets[0], gridDim.x, sFlag)) return;
     if (tid < 256) {
         const int s2 = tid >> 4, j = tid & 15;
         double a = 0.0;
         if (s2 < S)
-            for (int x = j; x < (int)gridDim.x; x += 16) a += P.blk_sums[(size_t)x * S + s2];
+            for (int x = j; x < (int)gridDim.x; x += 16) a += ld_agent(&P.blk_sums[(size_t)x * S + s2]);
         sD[tid] = a;
     }
     __syncthreads();
