@@ -771,8 +771,9 @@ __device__ __forceinline__ int build_shaft_list(const BvhNode* __restrict__ bvh,
 // STATS builds count BVH visits with global atomics inside the pair loop; that store makes
 // the compiler give up scalar (SMEM) loads for nodes and triangles, so it is a separate,
 // debug-only instantiation.
+// amdgpu_num_sgpr: at most 90 allocatable + 6 (VCC, FLAT_SCRATCH, XNACK) = 96, the most a CU still admits 7 blocks with
 template <int NT, bool STATS, bool SHAFT>
-__global__ __launch_bounds__(NT) void k_ff_tiles(TileParams P) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(98))) void k_ff_tiles(TileParams P) {
     const int t = blockIdx.x;
     const int o = P.tile0 + blockIdx.y;
     const bool t_owned = (t >= P.tile0) && (t < P.tile0 + P.nOwnedTiles);

@@ -2,7 +2,12 @@
 // same config.ini keys, loads the same .obj/.mtl scene through MeshS, builds the Lightning the
 // ini selects, converges it, and writes the per-patch result instead of opening a window.
 //
-//   daisyriot_cli [config.ini] [--passes n] [--out file.csv] [--ply file.ply] [--device d] [--no-matfile]
+//   daisyriot_cli [config.ini] [--passes n] [--out file.csv] [--ply file.ply] [--device d | --devices 0,1,..] [--no-matfile]
+//
+// Keys beyond the reference's (defaults = its compile-time constants): [acceleration] devices = 0,1,.. (GPUs the rows of
+// F are sharded over, one process), rays_per_patch (RAYS_PER_PATCH, Defines.h:25), seed (of the visibility samples);
+// [lightning] tolerance (convergence threshold; default 200 spectral / 1e-4 RGB, BW), max_passes, bins (number of
+// wavelengths from 200 to 600 nm; default 9 = main.cpp:94's {200,250,..,600}).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -10,6 +15,7 @@
 #include <fstream>
 #include <iostream>
 #include <memory>
+#include <sstream>
 
 #include "ini_reader.h"
 #include "lightning.h"
@@ -17,15 +23,24 @@
 
 using namespace daisy;
 
+static std::vector<int> parse_devices(const std::string& s) {
+    std::vector<int> d;
+    std::stringstream ss(s);
+    std::string tok;
+    while (std::getline(ss, tok, ','))
+        if (!tok.empty()) d.push_back(std::atoi(tok.c_str()));
+    return d;
+}
+
 int main(int argc, char** argv) {
-    std::string ini = "config.ini", out, ply;
-    int extra_passes = 0, device = 0;
+    std::string ini = "config.ini", out, ply, devices_arg;
+    int extra_passes = 0;
     bool use_matfile = true;
     for (int a = 1; a < argc; a++) {
         if (!std::strcmp(argv[a], "--passes") && a + 1 < argc) extra_passes = std::atoi(argv[++a]);
         else if (!std::strcmp(argv[a], "--out") && a + 1 < argc) out = argv[++a];
         else if (!std::strcmp(argv[a], "--ply") && a + 1 < argc) ply = argv[++a];
-        else if (!std::strcmp(argv[a], "--device") && a + 1 < argc) device = std::atoi(argv[++a]);
+        else if ((!std::strcmp(argv[a], "--device") || !std::strcmp(argv[a], "--devices")) && a + 1 < argc) devices_arg = argv[++a];
         else if (!std::strcmp(argv[a], "--no-matfile")) use_matfile = false;
         else ini = argv[a];
     }
@@ -37,15 +52,25 @@ int main(int argc, char** argv) {
     float emission_value = (float)reader.GetReal("lightning", "emission_value", -1);
     int method = (int)reader.GetInteger("lightning", "method", 0);
     bool cuda_on = reader.GetBoolean("acceleration", "cuda_on", false);
-    // extra key (default = effectively the reference's "no cap"): upper bound on converge passes
-    int max_passes = (int)reader.GetInteger("lightning", "max_passes", 100000);
+    LightningOptions opt;
+    // extra keys (defaults = the reference's constants)
+    opt.max_passes = (int)reader.GetInteger("lightning", "max_passes", 100000);     // the reference has no cap
+    opt.tolerance = (float)reader.GetReal("lightning", "tolerance", -1.0);         // < 0: 200 (spectral) / 1e-4 (RGB, BW)
+    opt.rays_per_patch = (int)reader.GetInteger("acceleration", "rays_per_patch", DR_RAYS_PER_PATCH);
+    opt.seed = (unsigned)reader.GetInteger("acceleration", "seed", 20191);
+    opt.devices = parse_devices(devices_arg.empty() ? reader.Get("acceleration", "devices", "0") : devices_arg);
+    if (opt.devices.empty()) opt.devices.push_back(0);
+    const int bins = (int)reader.GetInteger("lightning", "bins", 9);
     std::string scene = reader.Get("filepaths", "scene", "UNKNOWN");
     std::string mtl_dir = reader.Get("filepaths", "mtl_dir", "testscenes/");
     // F cache next to the scene: scene path minus its 4-character extension (main.cpp:80-82)
     std::string matfile = scene.size() > 4 ? scene.substr(0, scene.size() - 4) : scene;
     std::cout << "mat file path " << matfile << std::endl;
 
-    std::vector<float> wavelengths = { 200.0f, 250.0f, 300.0f, 350.0f, 400.0f, 450.0f, 500.0f, 550.0f, 600.0f };   // main.cpp:94
+    // main.cpp:94: {200, 250, .., 600}; `bins` other than 9 spreads that many wavelengths over the same range
+    std::vector<float> wavelengths;
+    if (bins < 1 || bins > DR_MAX_BINS) { std::cerr << "[lightning] bins must be 1.." << DR_MAX_BINS << "\n"; return 1; }
+    for (int b = 0; b < bins; b++) wavelengths.push_back(bins == 1 ? 400.0f : 200.0f + 400.0f * (float)b / (float)(bins - 1));
     try {
         auto t0 = std::chrono::high_resolution_clock::now();
         MeshS mesh(scene.c_str(), mtl_dir.c_str(), wavelengths);
@@ -53,7 +78,8 @@ int main(int argc, char** argv) {
         if (mesh.numtriangles == 0) { std::cerr << "no triangles loaded from " << scene << "\n"; return 1; }
         std::cout << "Number of triangles: " << mesh.numtriangles << std::endl;
         std::unique_ptr<Lightning> lightning(Lightning::get_lightning(method, mesh, emission_value, wavelengths, cuda_on,
-                                                                      use_matfile ? matfile.c_str() : nullptr, device, max_passes));
+                                                                      use_matfile ? matfile.c_str() : nullptr, opt));
+        if (lightning->ranks() > 1) std::cout << "Rows of the form-factor matrix sharded over " << lightning->ranks() << " GPUs" << std::endl;
         for (int k = 0; k < extra_passes; k++) lightning->increment_lightpass();    // key 'L'
         auto t1 = std::chrono::high_resolution_clock::now();
         dr_info info = lightning->info();

@@ -30,12 +30,20 @@ vec3 cie1931_xyz_fit(double w) {
     return vec3{ (float)x, (float)y, (float)z };
 }
 
+static bool read_fcache_body(std::ifstream& f, int N, std::vector<float>& dense);
+
 // Reader/writer of the reference's F cache (Lightning.h:21-74): ints rows, cols, nnz, outerSize, innerSize,
 // then float values[nnz], int outerIndex[outerSize] (not outerSize+1), int innerIndex[nnz] of the
 // column-major compressed matrix RadMat(i,j) = F(i->j).
-bool read_fcache(const char* path, int N, std::vector<float>& dense) {
+bool read_fcache(const char* path, int N, std::vector<float>& dense) { return read_fcache_status(path, N, dense) == FCACHE_OK; }
+
+FCacheStatus read_fcache_status(const char* path, int N, std::vector<float>& dense) {
     std::ifstream f(path, std::ios::binary);
-    if (!f.is_open()) return false;
+    if (!f.is_open()) return FCACHE_ABSENT;
+    return read_fcache_body(f, N, dense) ? FCACHE_OK : FCACHE_UNREADABLE;
+}
+
+static bool read_fcache_body(std::ifstream& f, int N, std::vector<float>& dense) {
     int hdr[5];
     f.read((char*)hdr, sizeof hdr);
     if (!f || hdr[0] != N || hdr[1] != N || hdr[2] < 0 || hdr[3] != N) return false;
@@ -83,10 +91,11 @@ void chk(int rc, const char* what) {
 class LightningHIP : public Lightning {
 public:
     LightningHIP(int method, MeshS& mesh, float emission_value, const std::vector<float>& wavelengths, bool cuda_rule,
-                 const char* matfile, int device, int max_passes)
-        : method_(method), max_passes_(max_passes), mesh_(mesh) {
+                 const char* matfile, const LightningOptions& opt)
+        : method_(method), max_passes_(opt.max_passes), mesh_(mesh) {
         N_ = mesh.numtriangles;
         if (N_ <= 0) throw HipError("mesh has no triangles");
+        if (opt.devices.empty()) throw HipError("no device given");
         const int n_mat = (int)mesh.materials.size();
         std::vector<float> E, M;
         if (method == 2) {                       // SpectralLightning (Lightning.h:114-139, 263-292)
@@ -122,41 +131,72 @@ public:
             }
             M.assign((size_t)n_mat, 1.0f);
         }
-        chk(dr_context_create(device, &ctx_), "dr_context_create");
+        if (opt.tolerance >= 0.0f) threshold_ = opt.tolerance;
+        // one process, all the listed GPUs: rows of F sharded over them (main.cpp:55-154 is one process too)
+        chk(dr_group_create(opt.devices.data(), (int)opt.devices.size(), &grp_), "dr_group_create");
+        world_ = (int)opt.devices.size();
+        for (int r = 0; r < world_; r++) {
+            dr_context* c = nullptr;
+            chk(dr_group_context(grp_, r, &c), "dr_group_context");
+            ctx_.push_back(c);
+        }
         std::vector<int32_t> tv((size_t)3 * N_), tn((size_t)3 * N_);
         for (int t = 0; t < N_; t++)
             for (int k = 0; k < 3; k++) {
                 tv[(size_t)3 * t + k] = mesh.triangleIndices[(size_t)t].vertex[k];
                 tn[(size_t)3 * t + k] = mesh.triangleIndices[(size_t)t].normal[k];
             }
-        chk(dr_scene_set_mesh(ctx_, &mesh.vertices[0].x, (int)mesh.vertices.size(), &mesh.normals[0].x,
-                              (int)mesh.normals.size(), tv.data(), tn.data(), N_), "dr_scene_set_mesh");
-        // initMat / initMatFromFile (Lightning.h:75-96)
+        chk(dr_group_set_mesh(grp_, &mesh.vertices[0].x, (int)mesh.vertices.size(), &mesh.normals[0].x,
+                              (int)mesh.normals.size(), tv.data(), tn.data(), N_), "dr_group_set_mesh");
+        for (int r = 0; r < world_; r++) {
+            int row0 = 0, nrows = 0, rpr = 0;
+            chk(dr_get_shard(ctx_[(size_t)r], &row0, &nrows, &rpr), "dr_get_shard");
+            row0_.push_back(row0); nrows_.push_back(nrows);
+        }
+        // initMat / initMatFromFile (Lightning.h:75-96).  Unlike the reference, a cache file that exists but cannot be this
+        // scene's (another N, truncated) is neither trusted nor overwritten, and a matrix too large for the cache's int
+        // indices is reported instead of silently re-traced on every run.
         std::vector<float> dense;
-        if (matfile && read_fcache(matfile, N_, dense)) {
-            chk(dr_formfactors_load_rows(ctx_, 0, N_, dense.data()), "dr_formfactors_load_rows");
+        const FCacheStatus st = matfile ? read_fcache_status(matfile, N_, dense) : FCACHE_ABSENT;
+        if (st == FCACHE_OK) {
+            for (int r = 0; r < world_; r++)
+                if (nrows_[(size_t)r] > 0)
+                    chk(dr_formfactors_load_rows(ctx_[(size_t)r], row0_[(size_t)r], nrows_[(size_t)r], dense.data() + (size_t)row0_[(size_t)r] * N_),
+                        "dr_formfactors_load_rows");
             std::printf("Deserialized matrix\n");
+            std::printf("(the cache file does not record which rule wrote it: [acceleration] cuda_on = %s now)\n", cuda_rule ? "true" : "false");
         } else {
-            std::vector<UV> rands = make_visibility_samples();
-            chk(dr_formfactors_assemble(ctx_, &rands[0].u, (int)rands.size(), DR_ORIGIN_EPS,
-                                        cuda_rule ? DR_RULE_INTEGRAND : DR_RULE_RECIPROCITY, 0), "dr_formfactors_assemble");
-            if (matfile && (size_t)N_ * N_ <= ((size_t)1 << 28)) {
-                dense.resize((size_t)N_ * N_);
-                chk(dr_formfactors_read_rows(ctx_, 0, N_, dense.data()), "dr_formfactors_read_rows");
-                write_fcache(matfile, N_, dense);
-                std::printf("Loaded & Serialized matrix\n");
+            if (st == FCACHE_UNREADABLE)
+                std::fprintf(stderr, "warning: %s exists but is not a form-factor cache of this scene (%d patches): left untouched, "
+                                     "form factors are assembled and NOT cached\n", matfile, N_);
+            std::vector<UV> rands = make_visibility_samples(opt.rays_per_patch, opt.seed);
+            chk(dr_group_assemble(grp_, &rands[0].u, (int)rands.size(), DR_ORIGIN_EPS,
+                                  cuda_rule ? DR_RULE_INTEGRAND : DR_RULE_RECIPROCITY, 0), "dr_group_assemble");
+            if (matfile && st == FCACHE_ABSENT) {
+                if ((size_t)N_ * N_ <= ((size_t)1 << 28)) {
+                    dense.resize((size_t)N_ * N_);
+                    for (int r = 0; r < world_; r++)
+                        if (nrows_[(size_t)r] > 0)
+                            chk(dr_formfactors_read_rows(ctx_[(size_t)r], row0_[(size_t)r], nrows_[(size_t)r], dense.data() + (size_t)row0_[(size_t)r] * N_),
+                                "dr_formfactors_read_rows");
+                    write_fcache(matfile, N_, dense);
+                    std::printf("Loaded & Serialized matrix\n");
+                } else {
+                    std::printf("form-factor matrix of %d patches not cached: the cache format indexes its entries with 32-bit ints "
+                                "(visual studio/Lightning.h:21-50)\n", N_);
+                }
             }
         }
-        chk(dr_solver_init(ctx_, S_, E.data(), M.data(), n_mat, mesh.materialIndexPerTriangle.data()), "dr_solver_init");
+        chk(dr_group_solver_init(grp_, S_, E.data(), M.data(), n_mat, mesh.materialIndexPerTriangle.data()), "dr_group_solver_init");
         // RadMat is sparse in the reference; here the all-zero blocks of the dense matrix are not read (same bits out)
-        chk(dr_solver_skip_zero_blocks(ctx_, 1), "dr_solver_skip_zero_blocks");
+        for (dr_context* c : ctx_) chk(dr_solver_skip_zero_blocks(c, 1), "dr_solver_skip_zero_blocks");
         B_.assign((size_t)N_ * S_, 0.0f);
         refresh();
         numpasses_ = 0;
         std::printf("Lightning has been initialized\n");
         converge_lightning();
     }
-    ~LightningHIP() override { dr_context_destroy(ctx_); }
+    ~LightningHIP() override { dr_group_destroy(grp_); }
 
     // rgb_color_cache of the reference (Lightning.h:168-183, 332-334, 406-408), filled on the device
     vec3 get_color_of_patch(int i) override { return rgb_[(size_t)i]; }
@@ -170,43 +210,61 @@ public:
         }
         if (adj.empty()) adj.push_back(0);
         std::vector<vec3> out(V);
-        chk(dr_display_vertex_colors(ctx_, nullptr, off.data(), adj.data(), (int)V, &out[0].x), "dr_display_vertex_colors");
+        // one rank: the colours are still on the device; several: every rank coloured its own rows, hand all of them over
+        chk(dr_display_vertex_colors(ctx_[0], world_ == 1 ? nullptr : &rgb_[0].x, off.data(), adj.data(), (int)V, &out[0].x),
+            "dr_display_vertex_colors");
         return out;
     }
     void converge_lightning() override {
         int it = 0;
-        chk(dr_solver_converge(ctx_, threshold_, per_bin_ ? 1 : 0, max_passes_, &it), "dr_solver_converge");
+        chk(dr_group_solver_converge(grp_, threshold_, per_bin_ ? 1 : 0, max_passes_, &it), "dr_group_solver_converge");
         numpasses_ += it;
         refresh();
     }
     void increment_lightpass() override {
-        chk(dr_solver_step(ctx_, 1, nullptr), "dr_solver_step");
+        chk(dr_group_solver_step(grp_, 1, nullptr), "dr_group_solver_step");
         numpasses_++;
         refresh();
     }
     void reset() override {
-        chk(dr_solver_reset(ctx_), "dr_solver_reset");
+        chk(dr_group_solver_reset(grp_), "dr_group_solver_reset");
         numpasses_ = 0;
         refresh();
     }
     int passes() const override { return numpasses_; }
-    float residual_light() override { float r = 0; chk(dr_solver_step(ctx_, 0, &r), "dr_solver_step"); return r; }
+    float residual_light() override { float r = 0; chk(dr_group_solver_step(grp_, 0, &r), "dr_group_solver_step"); return r; }
     const std::vector<float>& lightningvalues() const override { return B_; }
     int bins() const override { return S_; }
-    dr_info info() override { dr_info i; chk(dr_get_info(ctx_, &i), "dr_get_info"); return i; }
+    int ranks() const override { return world_; }
+    dr_info info() override {
+        dr_info i;
+        chk(dr_get_info(ctx_[0], &i), "dr_get_info");
+        for (int r = 1; r < world_; r++) {
+            dr_info j;
+            chk(dr_get_info(ctx_[(size_t)r], &j), "dr_get_info");
+            if (j.last_assemble_ms > i.last_assemble_ms) i.last_assemble_ms = j.last_assemble_ms;
+            i.pairs_traced += j.pairs_traced;
+        }
+        return i;
+    }
 
 private:
     void refresh() {
-        chk(dr_solver_read(ctx_, B_.data(), nullptr), "dr_solver_read");
+        chk(dr_group_solver_read(grp_, B_.data(), nullptr), "dr_group_solver_read");
         rgb_.resize((size_t)N_);
         const int mode = method_ == 2 ? DR_DISPLAY_SPECTRAL : (method_ == 1 ? DR_DISPLAY_RGB : DR_DISPLAY_BW);
-        chk(dr_display_patch_colors(ctx_, mode, method_ == 2 ? &xyz_[0].x : nullptr, &rgb_[0].x), "dr_display_patch_colors");
+        for (int r = 0; r < world_; r++)
+            if (nrows_[(size_t)r] > 0)
+                chk(dr_display_patch_colors(ctx_[(size_t)r], mode, method_ == 2 ? &xyz_[0].x : nullptr, &rgb_[(size_t)row0_[(size_t)r]].x),
+                    "dr_display_patch_colors");
     }
-    int method_, max_passes_, N_ = 0, S_ = 0, numpasses_ = 0;
+    int method_, max_passes_, N_ = 0, S_ = 0, numpasses_ = 0, world_ = 1;
     float threshold_ = 0;
     bool per_bin_ = false;
     MeshS& mesh_;
-    dr_context* ctx_ = nullptr;
+    dr_group* grp_ = nullptr;
+    std::vector<dr_context*> ctx_;        // owned by grp_
+    std::vector<int> row0_, nrows_;
     std::vector<float> B_;
     std::vector<vec3> xyz_, rgb_;
 };
@@ -214,10 +272,18 @@ private:
 }  // namespace
 
 Lightning* Lightning::get_lightning(int method, MeshS& mesh, float& emissionval, std::vector<float> wavelengthsvec,
-                                    bool cuda_enabled, const char* matfile, int device, int max_passes) {
+                                    bool cuda_enabled, const char* matfile, const LightningOptions& options) {
     if (method < 0 || method > 2)       // the reference falls off the end of the function here (Lightning.h:448-456)
         throw HipError("lightning method must be 0 (BW), 1 (RGB) or 2 (Spectral)");
-    return new LightningHIP(method, mesh, emissionval, wavelengthsvec, cuda_enabled, matfile, device, max_passes);
+    return new LightningHIP(method, mesh, emissionval, wavelengthsvec, cuda_enabled, matfile, options);
+}
+
+Lightning* Lightning::get_lightning(int method, MeshS& mesh, float& emissionval, std::vector<float> wavelengthsvec,
+                                    bool cuda_enabled, const char* matfile, int device, int max_passes) {
+    LightningOptions o;
+    o.devices = { device };
+    o.max_passes = max_passes;
+    return get_lightning(method, mesh, emissionval, wavelengthsvec, cuda_enabled, matfile, o);
 }
 
 }  // namespace daisy

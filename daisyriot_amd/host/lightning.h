@@ -22,10 +22,23 @@ std::vector<UV> make_visibility_samples(int K = DR_RAYS_PER_PATCH, unsigned seed
 vec3 cie1931_xyz_fit(double wavelength);
 
 // F-matrix disk cache in the reference's format (Lightning.h:21-74): dense N x N row-major <-> file
+enum FCacheStatus { FCACHE_OK = 0, FCACHE_ABSENT = 1, FCACHE_UNREADABLE = 2 };   // unreadable: another N, truncated, bad indices
+FCacheStatus read_fcache_status(const char* path, int N, std::vector<float>& dense);
 bool read_fcache(const char* path, int N, std::vector<float>& dense);
 void write_fcache(const char* path, int N, const std::vector<float>& dense);
 
 struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// What the reference fixes at compile time (RAYS_PER_PATCH, the srand seed, the thresholds 200 / 1e-4, one GPU), as
+// run-time options; the defaults are the reference's constants.  Filled from config.ini by daisyriot_cli:
+// [acceleration] devices, rays_per_patch, seed; [lightning] tolerance, max_passes (bins selects the wavelengths).
+struct LightningOptions {
+    std::vector<int> devices = { 0 };   // HIP ordinals; rows of F are sharded over them (one process, dr_group)
+    int rays_per_patch = DR_RAYS_PER_PATCH;     // visual studio/Defines.h:25
+    unsigned seed = 20191;                      // of the K (u,v) samples (the reference: srand(time()))
+    float tolerance = -1.0f;                    // < 0: the reference's threshold of the method (200 spectral, 1e-4 RGB / BW)
+    int max_passes = 100000;                    // cap of converge_lightning (the reference has none)
+};
 
 class Lightning {
 public:
@@ -35,6 +48,8 @@ public:
     static Lightning* get_lightning(int method, MeshS& mesh, float& emissionval, std::vector<float> wavelengthsvec,
                                     bool cuda_enabled = false, const char* matfile = nullptr, int device = 0,
                                     int max_passes = 100000);
+    static Lightning* get_lightning(int method, MeshS& mesh, float& emissionval, std::vector<float> wavelengthsvec,
+                                    bool cuda_enabled, const char* matfile, const LightningOptions& options);
     virtual ~Lightning() {}
     virtual vec3 get_color_of_patch(int) = 0;
     virtual void converge_lightning() = 0;
@@ -45,7 +60,8 @@ public:
     virtual float residual_light() = 0;
     virtual const std::vector<float>& lightningvalues() const = 0;   // N x S patch-major
     virtual int bins() const = 0;
-    virtual dr_info info() = 0;
+    virtual dr_info info() = 0;          // of rank 0 (assembly time = the slowest rank's)
+    virtual int ranks() const = 0;       // GPUs the rows are sharded over
     // per-vertex display colour = mean over MeshS::trianglesPerVertex (Drawer.cpp:161-186), on the device
     virtual std::vector<vec3> vertex_colors() = 0;
 };

@@ -45,6 +45,7 @@ def lib():
         L.orc_p2p_integrand_literal.argtypes = [C.POINTER(_Mesh), C.c_int, C.c_int]
         L.orc_patch_records.argtypes = [C.POINTER(_Mesh), fp, fp, fp, fp]
         L.orc_integrand_rows.argtypes = [C.POINTER(_Mesh), C.c_int, C.c_int, fp]
+        L.orc_integrand_rows_cuda_twin.argtypes = [C.POINTER(_Mesh), C.c_int, C.c_int, fp]
         L.orc_uv2xyz.argtypes = [C.POINTER(_Mesh), C.c_int, C.c_float, C.c_float, fp]
         L.orc_closest_hit.restype = C.c_int
         L.orc_closest_hit.argtypes = [C.POINTER(_Mesh), fp, fp, fp]
@@ -113,10 +114,12 @@ def patch_records(mesh):
     return cen, sa, nrm, area
 
 
-def integrand_rows(mesh, row0=0, nrows=None):
+def integrand_rows(mesh, row0=0, nrows=None, cuda_twin=False):
+    """stored unoccluded integrand rows; cuda_twin: with the mixed float/double arithmetic of the reference's CUDA
+    kernel (parallellism.cu:197-207) instead of triangle_math.cpp's all-float form"""
     nrows = mesh.N - row0 if nrows is None else nrows
     out = np.empty((nrows, mesh.N), np.float32)
-    lib().orc_integrand_rows(mesh.ref, row0, nrows, _p(out))
+    (lib().orc_integrand_rows_cuda_twin if cuda_twin else lib().orc_integrand_rows)(mesh.ref, row0, nrows, _p(out))
     return out
 
 

@@ -174,6 +174,42 @@ void orc_integrand_rows(const orc_mesh* m, int row0, int nrows, float* out) {
     rec_free(&r);
 }
 
+/* The CUDA twin of the integrand (visual studio/parallellism.cu:197-207), which the reference runs when cuda_on = true:
+ * CUDART_PI is a double, so the denominator powf(length,2)*CUDART_PI, the division and the product with `surface` are
+ * evaluated in double and rounded to float once, where triangle_math.cpp:49-58 (M_PIf) rounds after every operation.
+ * The build follows the CPU file for both rules; these two functions exist to MEASURE that deviation
+ * (tests/test_oracle_cpu.py::test_cuda_twin_arithmetic_deviation). */
+static inline float point_ff_cuda_twin(v3 opos, v3 onrm, v3 dpos, v3 dnrm, float surface) {
+    float ff = 0;
+    float dot1 = v3_dot(onrm, v3_normalize(v3_sub(dpos, opos)));
+    float dot2 = v3_dot(dnrm, v3_normalize(v3_sub(opos, dpos)));
+    if (dot1 > 0 && dot2 > 0) {
+        float length = v3_length(v3_sub(dpos, opos));
+        ff = (float)((((double)(dot1 * dot2)) / ((double)(length * length) * 3.1415926535897931e+0)) * (double)surface);
+    }
+    return ff;
+}
+
+void orc_integrand_rows_cuda_twin(const orc_mesh* m, int row0, int nrows, float* out) {
+    patch_rec r = rec_build(m);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < nrows; i++)
+        for (int j = 0; j < m->N; j++) {
+            const int a = row0 + i;
+            v3 on = v3_ld(r.nrm + 3 * (long)a), dn = v3_ld(r.nrm + 3 * (long)j);
+            float ff = 0;
+            for (int s = 0; s < 4; s++) {
+                v3 op = v3_ld(r.cen + 12 * (long)a + 3 * s);
+                for (int t = 0; t < 4; t++) {
+                    v3 dp = v3_ld(r.cen + 12 * (long)j + 3 * t);
+                    ff = ff + point_ff_cuda_twin(op, on, dp, dn, r.sa[4 * (long)a + s] * r.sa[4 * (long)j + t]);
+                }
+            }
+            out[(long)i * m->N + j] = stored(ff / r.area[a]);
+        }
+    rec_free(&r);
+}
+
 /* triangle_math.cpp:3-9: a + u*(b-a) + v*(c-a) */
 static inline v3 uv2xyz(const orc_mesh* m, int tri, float u, float v) {
     v3 a = vert(m, tri, 0), b = vert(m, tri, 1), c = vert(m, tri, 2);

@@ -66,6 +66,8 @@ void orc_patch_records(const orc_mesh* m, float* cen, float* sub_area,
 
 /* Stored integrand rows: out[(r-row0)*N + c] = F>0 ? F : 0 (parallellism.cu:98-108). */
 void orc_integrand_rows(const orc_mesh* m, int row0, int nrows, float* out);
+/* the same with the arithmetic of the reference's CUDA kernel (parallellism.cu:197-207: double pi, double product) */
+void orc_integrand_rows_cuda_twin(const orc_mesh* m, int row0, int nrows, float* out);
 
 /* uv2xyz, triangle_math.cpp:3-9 */
 void orc_uv2xyz(const orc_mesh* m, int tri, float u, float v, float out[3]);

@@ -112,3 +112,27 @@ def test_ray_count_exchange_assignment_is_a_balanced_partition():
         who = np.array([api.vis_exchange_tracer(N, world, int(x) * 64, int(y) * 64) for x, y in zip(t1.ravel()[::7], t2.ravel()[::7])])
         assert abs((who == r1).mean() - 0.5) < 0.02 and set(who.tolist()) == {r1, r2}
     assert api.vis_exchange_tracer(N, world, -1, 0) == -1 and api.vis_exchange_tracer(N, world, 0, N) == -1
+
+
+def test_tile_kernel_register_budget():
+    """k_ff_tiles' hand-written BVH walk names its node registers (s[48:63]) instead of letting the compiler allocate them.
+    Static check on the built code object's resource usage: the named registers lie inside the kernel's SGPR allocation, nothing
+    spills, and the count stays at or below 96 -- above that a CU admits 6 instead of 7 blocks (MI355X_MICROARCH.md, Residency)"""
+    path = os.path.join(ROOT, "daisyriot_amd", "lib", "geom_kernels.resources.txt")
+    if not os.path.exists(path):
+        pytest.skip("library built without the resource report")
+    text = open(path).read()
+    blocks = re.split(r"remark: Function Name: ", text)[1:]
+    tile = [b for b in blocks if b.startswith("_ZN2dr10k_ff_tilesILi256ELb0ELb0EEE")]
+    assert len(tile) == 1, "default tile kernel not found in the resource report"
+    def val(name):
+        return int(re.search(name + r": (\d+)", tile[0]).group(1))
+    assert 64 <= val("TotalSGPRs") <= 96
+    # (a few SGPRs parked in VGPR lanes outside the pair loop are fine; memory spills are not)
+    assert val("SGPRs Spill") <= 4 and val("VGPRs Spill") == 0 and val(r"ScratchSize \[bytes/lane\]") == 0
+    assert val("VGPRs") <= 64                                   # 8 waves per SIMD by registers
+    src = open(os.path.join(ROOT, "daisyriot_amd", "csrc", "geom_kernels.hip")).read()
+    named = sorted(set(int(x) for x in re.findall(r'#define DR_[AB][0-7] "s(\d+)"', src.split("#else")[0])))
+    assert named == list(range(48, 64))
+    for n in named:                                             # every named register is in the asm statement's clobber list
+        assert '"s%d"' % n in src.split("#define DR_WALK_CLOBBERS")[1].split("\n")[0]

@@ -128,3 +128,53 @@ def test_spectral_scene_with_a_generated_coefficient_table(tmp_path):
     assert not np.allclose(d1[:, 4:], d0[:, 4:])          # the table's spectra, not the stand-in's
     # the upsampled reflectances stay below 1: four passes lose energy in every bin that carries any
     assert d1[:, 4:].sum() > 0
+
+
+def test_cli_shards_over_several_devices_and_reads_the_extra_ini_keys(tmp_path):
+    """[acceleration] devices = 0,0,0 : one process, three ranks (here all on GPU 0: the one-GPU rehearsal of the dr_group path,
+    exchange by peer copies) -- same passes, same radiance as one device; rays_per_patch / seed / tolerance / bins are honoured"""
+    _write_scene(tmp_path, 700, 1, True)
+    out1, d1 = _run(tmp_path, "--no-matfile")
+    ini = (tmp_path / "config.ini").read_text()
+    (tmp_path / "config.ini").write_text(ini + "devices = 0,0,0\n")
+    out3, d3 = _run(tmp_path, "--no-matfile", "--ply", str(tmp_path / "v.ply"))
+    assert "sharded over 3 GPUs" in out3
+    p1 = [l for l in out1.splitlines() if l.startswith("Number of light passes")][0].split(".")[0]
+    assert p1 in out3                                                     # the same pass count
+    assert np.allclose(d1, d3, rtol=2e-6, atol=1e-9)
+    assert np.array_equal(d1[:, 1:4], d1[:, 4:7]) and np.array_equal(d3[:, 1:4], d3[:, 4:7])
+    # --devices on the command line overrides the ini
+    out2, d2 = _run(tmp_path, "--no-matfile", "--devices", "0,0")
+    assert "sharded over 2 GPUs" in out2 and np.allclose(d1, d2, rtol=2e-6, atol=1e-9)
+    # fewer rays, another seed: another (coarser) visibility estimate; a loose tolerance: fewer passes
+    (tmp_path / "config.ini").write_text(ini + "rays_per_patch = 8\nseed = 7\n[lightning]\ntolerance = 0.05\n")
+    out4, d4 = _run(tmp_path, "--no-matfile")
+    n1 = int(p1.split()[-1])
+    n4 = int([l for l in out4.splitlines() if l.startswith("Number of light passes")][0].split(".")[0].split()[-1])
+    assert 0 < n4 < n1 and not np.allclose(d1[:, 4:], d4[:, 4:], rtol=1e-3)
+    uv8 = np.zeros((8, 2), np.float32)
+    C.CDLL(api.LIB_PATH, mode=C.RTLD_GLOBAL)
+    C.CDLL(HOST).drh_visibility_samples(8, C.c_uint(7), uv8.ctypes.data_as(C.c_void_p))
+    sc = scenes.cornell_box(700, S=3)
+    with api.Context(0) as c:
+        c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+        c.assemble(uv8)
+        c.solver_init(sc.emission(7.0), sc.M, sc.mat_of_patch)
+        assert c.converge(0.05, per_bin=True, max_iters=1000) == n4
+        B, _ = c.read()
+    assert np.allclose(d4[:, 4:7], B, rtol=1e-6, atol=1e-9)
+
+
+def test_spectral_bins_key_and_unreadable_cache(tmp_path):
+    _write_scene(tmp_path, 300, 2, True)
+    ini = (tmp_path / "config.ini").read_text()
+    (tmp_path / "config.ini").write_text(ini.replace("method = 2", "method = 2\nbins = 5"))
+    out, d = _run(tmp_path, "--no-matfile", "--passes", "2")
+    assert d.shape == (300, 4 + 5) and np.isfinite(d).all()
+    # a file at the cache path that is not this scene's matrix is neither trusted nor overwritten (the reference would
+    # load whatever is there: Lightning.h:84-96)
+    junk = np.arange(64, dtype=np.int32).tobytes()
+    (tmp_path / "box").write_bytes(junk)
+    r = subprocess.run([CLI, str(tmp_path / "config.ini"), "--out", str(tmp_path / "o.csv")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "not a form-factor cache of this scene" in r.stderr
+    assert (tmp_path / "box").read_bytes() == junk

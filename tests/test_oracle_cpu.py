@@ -223,3 +223,38 @@ def test_integrand_statistics_of_the_reference_run(name, nnz, rs_mean, rs_max):
     rs = Fu.sum(axis=1, dtype=np.float64)
     assert abs((Fu > 0).mean() - nnz) < 0.0005
     assert abs(rs.mean() - rs_mean) < 0.0005 and abs(rs.max() - rs_max) < 0.005
+
+
+@pytest.mark.parametrize("name", ["cornellbox_blacklight", "colorballs"])
+def test_cuda_twin_arithmetic_deviation(name):
+    """The build evaluates the integrand as the reference's CPU file does (triangle_math.cpp:49-58, all float, M_PIf) under
+    BOTH assembly rules; with cuda_on = true the reference itself runs the CUDA twin, which divides by a double pi and
+    multiplies in double (parallellism.cu:197-207).  How far apart are the two?  Measured on the reference's own scenes:
+    a few float ulps per form factor, 1e-6 of the converged radiance -- two orders below north_star's 1e-4 bar."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "scene_%s.npz" % name))
+    m = ob.Mesh(g["vertices"], g["normals"], g["tri_v"], g["tri_n"])
+    N = m.N
+    Fa = ob.integrand_rows(m)
+    Fb = ob.integrand_rows(m, cuda_twin=True)
+    assert np.array_equal(Fa > 0, Fb > 0)                       # the same pairs see each other
+    nz = Fa > 0
+    rel = np.abs(Fa[nz].astype(np.float64) - Fb[nz]) / Fa[nz]
+    assert rel.max() < 1.5e-6 and rel.mean() < 2e-7             # 16 terms of <= 1.5 ulp each, summed in float
+    # converged radiance (RGB rule, unoccluded F scaled to a contraction so that the iteration converges like the real one)
+    Kd, Ke, mat = g["Kd"], g["Ke"], g["mat"]
+    M = np.zeros((Kd.shape[0], 3, 3), np.float32)
+    for k in range(Kd.shape[0]):
+        M[k] = np.diag(np.clip(Kd[k], 0, 0.8))
+    E = np.where(Ke[mat] > 0, Ke[mat] * np.float32(7.0), 0).astype(np.float32)
+    if not (E > 0).any():
+        E[: max(1, N // 200)] = 7.0
+    scale = np.float32(0.9 / max(Fa.sum(axis=1).max(), 1e-9))
+    out = []
+    for F in (Fa, Fb):
+        Fs = (F * scale).astype(np.float32)
+        it, R, B = ob.converge(Fs, M, mat, E, 1e-4, True, 400)
+        out.append((it, B))
+    assert out[0][0] == out[1][0]
+    dB = np.abs(out[0][1] - out[1][1]) / (np.abs(out[0][1]).max(axis=0) + 1e-30)
+    assert dB.max() < 2e-6
+    print("%s: max rel dF %.2e, mean %.2e, max rel dB %.2e after %d passes" % (name, rel.max(), rel.mean(), dB.max(), out[0][0]))
