@@ -502,12 +502,19 @@ static hipError_t launch_cfg(hipStream_t st, const SweepParams& p) {
 // single pass is fastest; below that, cut columns until there are about 1024 blocks, each block
 // keeping at least 8 tiles (the ranges need not be equal).  Measured at N = 65 536 on one
 // MI355X (profiles/r01/sweep_shards.md): 8192 rows 0.437 ms unsplit -> 0.342 ms with 4 ranges.
+// rows per wave of k_sweep: 8 (4 above 8 bins: the accumulators are RR*S registers); DR_SWEEP_RR=4 tries 4 below too
+static int sweep_rr(int S) {
+    static int rr = -1;
+    if (rr < 0) { const char* e = getenv("DR_SWEEP_RR"); rr = e ? atoi(e) : 8; }
+    return (S <= 8 && rr != 4) ? 8 : 4;
+}
+
 // rows per workgroup of the pass kernel launch_sweep picks: k_sweep: 4 waves x 8 rows; k_sweep_mfma: 4 x 16
 static int sweep_rows_per_block(int S) {
     static int mfma = -1;
     if (mfma < 0) { const char* e = getenv("DR_SWEEP_MFMA"); mfma = e ? atoi(e) : 1; }
     if (S > 8 && mfma) return 4 * MT_ROWS;
-    return (S <= 8) ? 32 : 16;
+    return 4 * sweep_rr(S);
 }
 int sweep_row_blocks(int nrows, int S) {
     const int rpb = sweep_rows_per_block(S);
@@ -531,8 +538,8 @@ template <int S>
 static hipError_t launch_sweep_s(hipStream_t st, const SweepParams& p) {
     // 8 rows per wave (4 above 8 bins: the accumulators are RR*S registers), 4 waves per block,
     // non-temporal F loads: measured best on MI355X (profiles/r01/sweep_variants.md)
-    constexpr int RR = (S <= 8) ? 8 : 4;
-    return launch_cfg<S, RR, 4, 1, true>(st, p);
+    if (S <= 8 && sweep_rr(S) == 8) return launch_cfg<S, 8, 4, 1, true>(st, p);
+    return launch_cfg<S, 4, 4, 1, true>(st, p);
 }
 
 static hipError_t launch_sweep_mfma(hipStream_t st, const SweepParams& p) {
