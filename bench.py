@@ -212,6 +212,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-zero-block-report", action="store_true",
                     help="skip the extra passes with zero-block skipping (keeps a kernel profile of this run to the dense pass)")
+    ap.add_argument("--no-converge-report", action="store_true",
+                    help="skip the extra passes through dr_solver_converge (keeps a kernel profile of this run to plain passes)")
     ap.add_argument("--rehearse-comm", action="store_true",
                     help="single rank only: still create the torch process group and the library's RCCL communicator "
                          "(all-gather of one chunk per pass), to rehearse the multi-GPU code path on a one-GPU box")
@@ -321,17 +323,19 @@ def main():
 
     # ---- the same passes through dr_solver_converge: the convergence test fused into the pass (sums in the residual's
     # tails, decision on the device, the host looks once per 8 queued passes) -- reported beside the headline
-    ctx.reset()
-    ctx.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    it = ctx.converge(-1.0, per_bin=False, max_iters=args.steps)
-    ctx.synchronize()
-    barrier()
-    dt_conv = max(p[0] for p in gather_f64([time.perf_counter() - t0]))
-    converge_report = {"iters_per_s": it / dt_conv, "ms_per_pass": dt_conv / max(it, 1) * 1e3, "passes": it,
-                       "note": "dr_solver_converge with a threshold that is never met: %d passes queued in batches of 8, "
-                               "convergence sums formed inside the pass and gathered with the residual" % it}
+    converge_report = None
+    if not args.no_converge_report:
+        ctx.reset()
+        ctx.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        it = ctx.converge(-1.0, per_bin=False, max_iters=args.steps)
+        ctx.synchronize()
+        barrier()
+        dt_conv = max(p[0] for p in gather_f64([time.perf_counter() - t0]))
+        converge_report = {"iters_per_s": it / dt_conv, "ms_per_pass": dt_conv / max(it, 1) * 1e3, "passes": it,
+                           "note": "dr_solver_converge with a threshold that is never met: %d passes queued in batches of 8, "
+                                   "convergence sums formed inside the pass and gathered with the residual" % it}
 
     # ---- the same passes with the optional zero-block skipping (reported beside the headline, never in it) ----
     skip_report = None

@@ -26,7 +26,7 @@ res = {"workload": {"patches": 65536, "bins": 8, "world": 1}, "kernel_source_sha
        "correction": "gfx950: FETCH_SIZE reports half the bytes of a wide coalesced stream (x2); WRITE_SIZE exact; units KiB "
                      "(MI355X_MICROARCH.md, HBM)",
        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace --output-format csv -- python3 bench.py "
-                  "--no-cpu-baseline --no-zero-block-report --steps 6 --warmup 2"}
+                  "--no-cpu-baseline --no-zero-block-report --no-converge-report --steps 6 --warmup 2"}
 res["commit"] = os.environ.get("DR_HEAD")
 if sweep:
     k = sweep[0]
