@@ -39,6 +39,19 @@ struct BvhNode {
 };                      // 32 B: one s_load_dwordx8
 constexpr int BVH_END = 0x7ffffff8;
 
+// Per-patch PATH RECORDS.  Every ray of a pair (lo, hi) starts on patch lo and ends on patch hi, so it is inside every
+// ancestor of the two patches' leaves: testing those nodes (a quarter of a walk from the root) tells nothing.  What a
+// walk does need are the SIBLINGS hanging off the two root-to-leaf paths -- together with the two leaves they cover the
+// whole tree.  They are the same for every pair the patch takes part in, so the build writes them out once per patch:
+// PATH_RECS records in root-to-leaf order, record d-1 = the sibling of the path's node at depth d, a copy of its box
+// with where to go on a hit: {c, h, start, end} -- an internal sibling's subtree is the node range [start, end) past its
+// own (already tested) node; a leaf sibling has end = -1 and start = its leaf code.  PathHdr: depth of the patch's leaf
+// (-1: deeper than PATH_RECS, such patches are walked from the root), the path's turns (bit d-1 set: right child at
+// depth d), the leaf code of the patch's own leaf.  The pair's walk streams the records (addresses known up front: no
+// pointer chasing), and only enters the tree below a sibling its rays touch.
+constexpr int PATH_RECS = 32;
+struct PathHdr { int depth; unsigned turns; int leaf; int pad; };
+
 constexpr int LEAF_MAX = 2;     // subtrees of up to this many triangles are collapsed into one leaf
                                 // (a leaf is fetched whole: LEAF_MAX x 16 SGPRs)
 
@@ -60,6 +73,8 @@ struct TileParams {
     const TriRec* tri;          // original order (ray generation)
     const TriRec* tri_sorted;   // Morton order, LEAF_MAX never-hit padding records at the end (leaf tests)
     const BvhNode* bvh;
+    const BvhNode* path_rec;    // [N][PATH_RECS] path records (see PathHdr); null: every walk starts at the root
+    const PathHdr* path_hdr;    // [N]
     const float* uv;          // K x 2
     unsigned long long* pairs_traced;   // [0] pairs traced, [1] BVH nodes visited, [2] leaves tested (wave level)
     int stats;                          // count [1],[2] too (debug; costs two atomics per pair)
@@ -137,7 +152,8 @@ hipError_t launch_patch_records(hipStream_t st, int N, const float* vtx, const f
                                 const int* tv, const int* tn, float box_pad, PatchRec* patch, TriRec* tri);
 hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float scene_lo[3],
                       const float scene_hi[3], float node_pad, BvhNode* nodes /* room for 2N */,
-                      TriRec* tri_sorted /* N + LEAF_MAX */, int* n_nodes_out);
+                      TriRec* tri_sorted /* N + LEAF_MAX */, int* n_nodes_out,
+                      BvhNode* path_rec /* N * PATH_RECS */, PathHdr* path_hdr /* N */);
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p);
 hipError_t launch_sweep(hipStream_t st, const SweepParams& p);
 int sweep_ksplit(int nrows, int S, int total_cols);

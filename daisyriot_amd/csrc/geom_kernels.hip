@@ -178,11 +178,12 @@ __global__ void k_refit(int N, const TriRec* __restrict__ tri, const int* __rest
                         const int* __restrict__ first, const int* __restrict__ last,
                         const int* __restrict__ parent, int* __restrict__ flags,
                         float* __restrict__ box /* (2N-1) x 6 */, int* __restrict__ esize /* 2N-1 */,
-                        TriRec* __restrict__ tri_sorted) {
+                        TriRec* __restrict__ tri_sorted, int* __restrict__ pos /* patch -> Morton position */) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
     const TriRec T = tri[sorted_tri[k]];
     tri_sorted[k] = T;
+    pos[sorted_tri[k]] = k;
     float lo[3], hi[3];
     tri_bounds(T, lo, hi);
     int id = N - 1 + k;
@@ -217,7 +218,8 @@ __global__ void k_refit(int N, const TriRec* __restrict__ tri, const int* __rest
 __global__ void k_emit(int N, const int* __restrict__ left, const int* __restrict__ first,
                        const int* __restrict__ last, const int* __restrict__ parent,
                        const float* __restrict__ box, const int* __restrict__ esize, float node_pad,
-                       const TriRec* __restrict__ tri_sorted, BvhNode* __restrict__ nodes) {
+                       const TriRec* __restrict__ tri_sorted, BvhNode* __restrict__ nodes,
+                       int* __restrict__ pre /* 2N-1, preset to -1: pre-order index of every node that is written */) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= 2 * N - 1) return;
     const bool internal = id < N - 1;
@@ -251,6 +253,40 @@ __global__ void k_emit(int N, const int* __restrict__ left, const int* __restric
         if (same) nd.tri |= 4;
     }
     nodes[idx] = nd;
+    pre[id] = idx;
+}
+
+// The path records of every patch (PathHdr, dr_internal.h): climb from the patch's leaf to the root, copying the sibling
+// of every node on the way.
+__global__ void k_paths(int N, const int* __restrict__ pos, const int* __restrict__ left, const int* __restrict__ right,
+                        const int* __restrict__ parent, const int* __restrict__ pre, const BvhNode* __restrict__ nodes,
+                        BvhNode* __restrict__ rec, PathHdr* __restrict__ hdr) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    int id = N - 1 + pos[p];
+    if (N > 1)
+        while (pre[id] < 0) id = parent[id];          // inside a collapsed subtree: up to the leaf that was written for it
+    PathHdr h;
+    h.leaf = nodes[N > 1 ? pre[id] : 0].tri;
+    h.turns = 0u; h.pad = 0;
+    int D = 0;
+    if (N > 1)
+        for (int c = id; c != 0; c = parent[c]) D++;
+    h.depth = D;
+    if (D > PATH_RECS) { h.depth = -1; hdr[p] = h; return; }
+    int d = D;
+    for (int c = id; d >= 1; d--) {
+        const int q = parent[c];
+        const bool is_right = right[q] == c;
+        const int sib = is_right ? left[q] : right[q];
+        if (is_right) h.turns |= 1u << (d - 1);
+        BvhNode nd = nodes[pre[sib]];
+        if (nd.tri >= 0) { nd.skip = nd.tri; nd.tri = -1; }                            // a leaf: start = its leaf code, end = -1
+        else { const int end = nd.skip; nd.skip = (pre[sib] + 1) * (int)sizeof(BvhNode); nd.tri = end; }   // below the sibling's own node
+        rec[(size_t)p * PATH_RECS + (d - 1)] = nd;
+        c = q;
+    }
+    hdr[p] = h;
 }
 
 __global__ void k_pad_tris(int N, TriRec* __restrict__ tri_sorted) {
@@ -264,7 +300,7 @@ __global__ void k_pad_tris(int N, TriRec* __restrict__ tri_sorted) {
 }
 
 hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[3], const float shi[3], float node_pad,
-                      BvhNode* nodes, TriRec* tri_sorted, int* n_nodes_out) {
+                      BvhNode* nodes, TriRec* tri_sorted, int* n_nodes_out, BvhNode* path_rec, PathHdr* path_hdr) {
     hipError_t e;
     unsigned long long *keys = nullptr, *keys2 = nullptr;
     int *vals = nullptr, *vals2 = nullptr, *ibuf = nullptr;
@@ -281,13 +317,15 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
     DR_TRY(hipMalloc(&keys2, sizeof(unsigned long long) * N));
     DR_TRY(hipMalloc(&vals, sizeof(int) * N));
     DR_TRY(hipMalloc(&vals2, sizeof(int) * N));
-    // left,right,first,last,flags: N-1 each; parent, esize: 2N-1 each
-    DR_TRY(hipMalloc(&ibuf, sizeof(int) * (5 * (size_t)N + 2 * nn)));
+    // left,right,first,last,flags: N-1 each; parent, esize, pre: 2N-1 each; pos: N
+    DR_TRY(hipMalloc(&ibuf, sizeof(int) * (6 * (size_t)N + 3 * nn)));
     DR_TRY(hipMalloc(&box, sizeof(float) * 6 * nn));
     {
         int* left = ibuf; int* right = ibuf + N; int* first = ibuf + 2 * (size_t)N;
         int* last = ibuf + 3 * (size_t)N; int* flags = ibuf + 4 * (size_t)N; int* parent = ibuf + 5 * (size_t)N;
         int* esize = parent + nn;
+        int* pre = esize + nn;
+        int* pos = pre + nn;
         const int nb = (N + 255) / 256;
         hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, st, N, tri, lo3, inv3, keys, vals);
         DR_TRY(hipGetLastError());
@@ -300,12 +338,17 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
             DR_TRY(hipGetLastError());
         }
         hipLaunchKernelGGL(k_refit, dim3(nb), dim3(256), 0, st, N, tri, vals2, left, right, first, last, parent, flags,
-                           box, esize, tri_sorted);
+                           box, esize, tri_sorted, pos);
         DR_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_pad_tris, dim3(1), dim3(64), 0, st, N, tri_sorted);
         DR_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_emit, dim3((int)((nn + 255) / 256)), dim3(256), 0, st, N, left, first, last, parent, box, esize, node_pad, tri_sorted, nodes);
+        DR_TRY(hipMemsetAsync(pre, 0xff, sizeof(int) * nn, st));
+        hipLaunchKernelGGL(k_emit, dim3((int)((nn + 255) / 256)), dim3(256), 0, st, N, left, first, last, parent, box, esize, node_pad, tri_sorted, nodes, pre);
         DR_TRY(hipGetLastError());
+        if (path_rec && path_hdr) {
+            hipLaunchKernelGGL(k_paths, dim3(nb), dim3(256), 0, st, N, pos, left, right, parent, pre, nodes, path_rec, path_hdr);
+            DR_TRY(hipGetLastError());
+        }
         // nodes written = size of the root's subtree (a lone triangle is its own root leaf)
         DR_TRY(hipMemcpyAsync(n_nodes_out, esize, sizeof(int), hipMemcpyDeviceToHost, st));
         DR_TRY(hipStreamSynchronize(st));
@@ -480,48 +523,43 @@ __device__ __forceinline__ void integrand_pair(const float* ri, const float* rj,
 #define DR_WALK_CLOBBERS "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95"
 #endif
 
-// Walk of one RANGE [off, end) of the threaded BVH for one wave of rays (segments [0,tmax] from org along dn);
-// returns the liveness mask with every lane cleared for which something in the range precedes its destination `hi`
-// (wave-uniform: one pair per wave).  A range is a run of whole subtrees that lie one after the other in the
-// pre-order array (the whole tree is the range [0, n_nodes*32)); every way out of a subtree lands exactly on the
-// first node after it, so leaving the range is only possible on a skip or after a leaf -- those two places compare
-// the offset with `end`, an entered interior node never does.
-//
-// The node index is wave-uniform.  The compiler's lowering of this loop spent ~20 scalar instructions per
-// node (the CU's single scalar unit serves all four SIMDs) beside the vector ones, so the interior-node
-// walk is written out by hand: one s_load_dwordx8 of the node at an SGPR byte offset, the 14-instruction
-// node test (node_hit_mask), one s_and with the liveness mask whose SCC is the branch condition, then
-// either offset += 32 (descend: the first child is the next node in pre-order) or offset = skip --
-// 7 scalar instructions for a node that is entered, 8 for one that is skipped.  The hand-written stretch
-// ends whenever a hit node is a leaf or the range is left.
-//
-// iv / kk: the per-ray constants of the node test (the ray's 1/d clamped to +-1e18, and -(org*iv)).
-template <bool STATS, bool RANGE>
-__device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restrict__ bvh, const TriRec* __restrict__ tri_sorted,
-                                                         unsigned off, const unsigned end, f3 org, f3 dn, f3 inv, f3 iv, f3 kk,
-                                                         float tmax, int hi, unsigned long long alive_m, int& n_visit, int& n_leaf) {
-    for (;;) {
-        if (RANGE && off >= end) break;
-        int leaf;
-        if (STATS) {
-            // counted variant of the same walk (debug builds only)
-            leaf = BVH_END;
-            while (off < end) {
-                const v8f raw = *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(bvh) + off);
-                const float nc[3] = { raw[0], raw[1], raw[2] }, nh[3] = { raw[3], raw[4], raw[5] };
-                const unsigned nd_skip = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
-                const int nd_leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
-                n_visit++;
-                const unsigned long long hb_m = node_hit_mask(nc, nh, iv, kk, tmax) & alive_m;
-                if (hb_m == 0ull) { off = nd_skip; continue; }
-                off += 32u;
-                if (nd_leaf >= 0) { leaf = nd_leaf; break; }
-            }
-        } else {
-            float t0, t1, t2, t3, t4, t5;
-            // two copies of the step, on node registers A and B (8 SGPRs each, fixed: DR_WALK_A/B below): while one node
-            // is tested the next one in pre-order (the first child, where a hit descends to) is already being fetched
-            // into the other set; a miss reloads its own set from the skip offset (RANGE: unless that leaves the range).
+// The triangles of one leaf against the wave's rays: the lanes (of alive_m) for which one of them precedes the destination
+// `hi` -- nearer, or at equal t with a lower id.  leaf = first*8 + (count-1) [+4: both triangles share one gate box].
+// The leaf's LEAF_MAX records (64 B each: triangle, id, gate box) are fetched together -- no dependent loads inside the
+// leaf; a triangle's Moller-Trumbore test only runs when some live lane passes its gate.
+__device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __restrict__ tri_sorted, int leaf, f3 org, f3 dn, f3 inv,
+                                                                float tmax, int hi, unsigned long long alive_m) {
+    const int first = leaf >> 3, cnt = (leaf & 3) + 1;
+    const bool same_gate = (leaf & 4) != 0;          // both triangles share one gate box (the halves of a quad)
+    const v4f* tp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(tri_sorted) + (unsigned)first * 64u);
+    v4f q[4 * LEAF_MAX];
+#pragma unroll
+    for (int c = 0; c < 4 * LEAF_MAX; c++) q[c] = tp[c];
+    unsigned long long blocked_m = 0ull, gm_prev = 0ull;
+#pragma unroll
+    for (int c = 0; c < LEAF_MAX; c++) {
+        const v4f A = q[4 * c], B = q[4 * c + 1], C3 = q[4 * c + 2], D = q[4 * c + 3];
+        const float blo[3] = { C3[2], C3[3], D[0] }, bhi[3] = { D[1], D[2], D[3] };
+        unsigned long long gm;
+        if (c == 1 && same_gate) gm = gm_prev;     // bit-identical box: the same mask
+        else gm = box_hit_mask(blo, bhi, org, inv, tmax) & alive_m;
+        gm_prev = gm;
+        if (gm == 0ull || c >= cnt) continue;      // (slots past the leaf's count belong to the next leaf)
+        const int tk = __builtin_amdgcn_readfirstlane(__float_as_int(C3[1]));
+        if (tk == hi) continue;                    // the destination: its t is tmax bit for bit, it never precedes itself
+        const f3 ta = f3{ A[0], A[1], A[2] };
+        const f3 te1 = f3{ A[3], B[0], B[1] };
+        const f3 te2 = f3{ B[2], B[3], C3[0] };
+        float tt;
+        const bool h = tri_hit(org, dn, ta, te1, te2, tt);
+        // closest hit is not `hi`: something nearer, or an equal-t hit of lower id
+        const unsigned long long bm = gm & __builtin_amdgcn_ballot_w64(h & ((tt < tmax) | ((tt == tmax) & (tk < hi))));
+        blocked_m |= bm;
+    }
+    return blocked_m;
+}
+
+// ---- the hand-written interior-node walk (used by walk_range and walk_pair below) ----
 #define DR_NODE_TEST(CX, CY, CZ, HX, HY, HZ)                                  \
                 "v_fma_f32 %[t0], " CX ", %[ix], %[kx]\n\t"                   \
                 "v_fma_f32 %[t1], " CY ", %[iy], %[ky]\n\t"                   \
@@ -586,50 +624,197 @@ __device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restri
                 : [bvh] "s"(bvh), [alive] "s"(alive_m), [end] "s"(end), [kx] "v"(kk.x), [ky] "v"(kk.y), [kz] "v"(kk.z), \
                   [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z), [tmax] "v"(tmax)                                      \
                 : DR_WALK_CLOBBERS, "vcc", "scc")
+
+// Walk of one RANGE [off, end) of the threaded BVH for one wave of rays (segments [0,tmax] from org along dn);
+// returns the liveness mask with every lane cleared for which something in the range precedes its destination `hi`
+// (wave-uniform: one pair per wave).  A range is a run of whole subtrees that lie one after the other in the
+// pre-order array (the whole tree is the range [0, n_nodes*32)); every way out of a subtree lands exactly on the
+// first node after it, so leaving the range is only possible on a skip or after a leaf -- those two places compare
+// the offset with `end`, an entered interior node never does.
+//
+// The node index is wave-uniform.  The compiler's lowering of this loop spent ~20 scalar instructions per
+// node (the CU's single scalar unit serves all four SIMDs) beside the vector ones, so the interior-node
+// walk is written out by hand: one s_load_dwordx8 of the node at an SGPR byte offset, the 14-instruction
+// node test (node_hit_mask), one s_and with the liveness mask whose SCC is the branch condition, then
+// either offset += 32 (descend: the first child is the next node in pre-order) or offset = skip --
+// 7 scalar instructions for a node that is entered, 8 for one that is skipped.  The hand-written stretch
+// ends whenever a hit node is a leaf or the range is left.
+//
+// iv / kk: the per-ray constants of the node test (the ray's 1/d clamped to +-1e18, and -(org*iv)).
+template <bool STATS, bool RANGE>
+__device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restrict__ bvh, const TriRec* __restrict__ tri_sorted,
+                                                         unsigned off, const unsigned end, f3 org, f3 dn, f3 inv, f3 iv, f3 kk,
+                                                         float tmax, int hi, unsigned long long alive_m, int& n_visit, int& n_leaf) {
+    for (;;) {
+        if (RANGE && off >= end) break;
+        int leaf;
+        if (STATS) {
+            // counted variant of the same walk (debug builds only)
+            leaf = BVH_END;
+            while (off < end) {
+                const v8f raw = *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(bvh) + off);
+                const float nc[3] = { raw[0], raw[1], raw[2] }, nh[3] = { raw[3], raw[4], raw[5] };
+                const unsigned nd_skip = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
+                const int nd_leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
+                n_visit++;
+                const unsigned long long hb_m = node_hit_mask(nc, nh, iv, kk, tmax) & alive_m;
+                if (hb_m == 0ull) { off = nd_skip; continue; }
+                off += 32u;
+                if (nd_leaf >= 0) { leaf = nd_leaf; break; }
+            }
+        } else {
+            float t0, t1, t2, t3, t4, t5;
+            // two copies of the step, on node registers A and B (8 SGPRs each, fixed: DR_WALK_A/B below): while one node
+            // is tested the next one in pre-order (the first child, where a hit descends to) is already being fetched
+            // into the other set; a miss reloads its own set from the skip offset (RANGE: unless that leaves the range).
             // without ranges there is no end compare at all: skips that leave the tree land on the sentinel node
             // (all-space box, leaf code BVH_END), which every live lane hits
             if (RANGE) { DR_WALK_ASM("s_cmp_lt_u32 %[off], %[end]\n\ts_cbranch_scc0 8f\n\t"); }
             else { DR_WALK_ASM(""); }
-#undef DR_WALK_ASM
-#undef DR_NODE_TEST
         }
         if (leaf == BVH_END) break;          // the range is done (or the tree's sentinel was reached)
         if (STATS) n_leaf++;
-        const int first = leaf >> 3, cnt = (leaf & 3) + 1;
-        const bool same_gate = (leaf & 4) != 0;          // both triangles share one gate box (the halves of a quad)
-        // Leaf: its LEAF_MAX records (64 B each: triangle, id, gate box) are fetched together --
-        // no dependent loads inside the leaf; a triangle's Moller-Trumbore test only runs when some
-        // live lane passes its gate.
-        const v4f* tp = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(tri_sorted) + (unsigned)first * 64u);
-        v4f q[4 * LEAF_MAX];
-#pragma unroll
-        for (int c = 0; c < 4 * LEAF_MAX; c++) q[c] = tp[c];
-        unsigned long long blocked_m = 0ull, gm_prev = 0ull;
-#pragma unroll
-        for (int c = 0; c < LEAF_MAX; c++) {
-            const v4f A = q[4 * c], B = q[4 * c + 1], C3 = q[4 * c + 2], D = q[4 * c + 3];
-            const float blo[3] = { C3[2], C3[3], D[0] }, bhi[3] = { D[1], D[2], D[3] };
-            unsigned long long gm;
-            if (c == 1 && same_gate) gm = gm_prev;     // bit-identical box: the same mask
-            else gm = box_hit_mask(blo, bhi, org, inv, tmax) & alive_m;
-            gm_prev = gm;
-            if (gm == 0ull || c >= cnt) continue;      // (slots past the leaf's count belong to the next leaf)
-            const int tk = __builtin_amdgcn_readfirstlane(__float_as_int(C3[1]));
-            if (tk == hi) continue;                    // the destination: its t is tmax bit for bit, it never precedes itself
-            const f3 ta = f3{ A[0], A[1], A[2] };
-            const f3 te1 = f3{ A[3], B[0], B[1] };
-            const f3 te2 = f3{ B[2], B[3], C3[0] };
-            float tt;
-            const bool h = tri_hit(org, dn, ta, te1, te2, tt);
-            // closest hit is not `hi`: something nearer, or an equal-t hit of lower id
-            const unsigned long long bm = gm & __builtin_amdgcn_ballot_w64(h & ((tt < tmax) | ((tt == tmax) & (tk < hi))));
-            blocked_m |= bm;
-        }
+        const unsigned long long blocked_m = leaf_blocked_mask(tri_sorted, leaf, org, dn, inv, tmax, hi, alive_m);
         alive_m &= ~blocked_m;
         if (alive_m == 0ull) break;
     }
     return alive_m;
 }
+
+// The walk of ONE PAIR over its path records (PathHdr, dr_internal.h) -- the shipped walk.  A state machine with one copy
+// of the hand-written node walk, one of the record stream and one of the leaf test:
+//   segments 0..2   path records, streamed (DR_STREAM_ASM: the next record is already loading while one is tested, their
+//                   addresses do not depend on any test): lo's records above the depth where the two paths part
+//                   [0, ell), lo's below it (ell, Dl) -- index ell, the branch that holds hi, is left out -- and hi's
+//                   below it (ell, Dh); a record whose box some live ray touches sends the walk into the subtree below
+//                   it (DR_WALK_ASM on the range [start, end)) or, for a leaf sibling, to the leaf test;
+//   then            the two patches' own leaves (one, if they share it).
+// from_root: no records (a patch deeper than PATH_RECS): one range, the whole tree.
+// Exactness: the records and the two leaves cover every leaf of the tree, each subtree is entered under the same node
+// tests as in a walk from the root -- only the ancestors' tests are not made, and every ray of the pair would pass those
+// (if one did not, this walk reaches more leaves than the walk from the root, never fewer; what is hit is decided per
+// triangle).
+#define DR_STREAM_ASM                                                                                                   \
+            asm volatile(                                                                                               \
+                "s_load_dwordx8 " DR_A_ALL ", %[base], %[roff] offset:0x0\n\t"                                          \
+                "s_waitcnt lgkmcnt(0)\n"                                                                                \
+                "1:\n\t"                                                                                                \
+                "s_load_dwordx8 " DR_B_ALL ", %[base], %[roff] offset:0x20\n\t"                                         \
+                DR_NODE_TEST(DR_A0, DR_A1, DR_A2, DR_A3, DR_A4, DR_A5)                                                  \
+                "s_cbranch_scc1 5f\n\t"                                                                                 \
+                "s_add_u32 %[roff], %[roff], 32\n\t"                                                                    \
+                "s_cmp_lt_u32 %[roff], %[rend]\n\t"                                                                     \
+                "s_cbranch_scc0 8f\n\t"                                                                                 \
+                "s_waitcnt lgkmcnt(0)\n"                                                                                \
+                "2:\n\t"                                                                                                \
+                "s_load_dwordx8 " DR_A_ALL ", %[base], %[roff] offset:0x20\n\t"                                         \
+                DR_NODE_TEST(DR_B0, DR_B1, DR_B2, DR_B3, DR_B4, DR_B5)                                                  \
+                "s_cbranch_scc1 6f\n\t"                                                                                 \
+                "s_add_u32 %[roff], %[roff], 32\n\t"                                                                    \
+                "s_cmp_lt_u32 %[roff], %[rend]\n\t"                                                                     \
+                "s_cbranch_scc0 8f\n\t"                                                                                 \
+                "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+                "s_branch 1b\n"                                                                                         \
+                "5:\n\t"                                                                                                \
+                "s_mov_b32 %[rs], " DR_A6 "\n\t"                                                                        \
+                "s_mov_b32 %[re], " DR_A7 "\n\t"                                                                        \
+                "s_branch 9f\n"                                                                                         \
+                "6:\n\t"                                                                                                \
+                "s_mov_b32 %[rs], " DR_B6 "\n\t"                                                                        \
+                "s_mov_b32 %[re], " DR_B7 "\n"                                                                          \
+                "9:\n\t"                                                                                                \
+                "s_add_u32 %[roff], %[roff], 32\n\t"                                                                    \
+                "s_mov_b32 %[hit], 1\n\t"                                                                               \
+                "s_branch 7f\n"                                                                                         \
+                "8:\n\t"                                                                                                \
+                "s_mov_b32 %[hit], 0\n"                                                                                 \
+                "7:\n\t"                                                                                                \
+                "s_waitcnt lgkmcnt(0)"                                                                                  \
+                : [roff] "+s"(roff), [hit] "=s"(r_hit), [rs] "=s"(r_start), [re] "=s"(r_end), [t0] "=&v"(t0), [t1] "=&v"(t1),       \
+                  [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5)                                        \
+                : [base] "s"(rbase), [alive] "s"(alive_m), [rend] "s"(rend), [kx] "v"(kk.x), [ky] "v"(kk.y), [kz] "v"(kk.z),      \
+                  [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z), [tmax] "v"(tmax)                                      \
+                : DR_WALK_CLOBBERS, "vcc", "scc")
+
+template <bool STATS>
+__device__ __forceinline__ unsigned long long walk_pair(const BvhNode* __restrict__ bvh, const TriRec* __restrict__ tri_sorted,
+                                                        const BvhNode* __restrict__ rec_lo, const BvhNode* __restrict__ rec_hi,
+                                                        int ell, int Dl, int Dh, int leaf_lo, int leaf_hi, bool from_root,
+                                                        unsigned end_all, f3 org, f3 dn, f3 inv, f3 iv, f3 kk, float tmax, int hi,
+                                                        unsigned long long alive_m, int& n_visit, int& n_leaf, int& n_stream) {
+    unsigned off = 0u, end = from_root ? end_all : 0u;
+    int seg = from_root ? 3 : -1;                     // record segment being streamed (0..2), then 3, 4: the own leaves, 5: done
+    unsigned roff = 0u, rend = 0u;
+    const BvhNode* rbase = rec_lo;
+    if (from_root) seg = 5;
+    for (;;) {
+        int leaf = BVH_END;
+        if (off < end) {
+            // inside a subtree: the hand-written walk up to the next leaf some live ray touches, or to the end of the range
+            if (STATS) {
+                while (off < end) {
+                    const v8f raw = *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(bvh) + off);
+                    const float nc[3] = { raw[0], raw[1], raw[2] }, nh[3] = { raw[3], raw[4], raw[5] };
+                    const unsigned nd_skip = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
+                    const int nd_leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
+                    n_visit++;
+                    const unsigned long long hb_m = node_hit_mask(nc, nh, iv, kk, tmax) & alive_m;
+                    if (hb_m == 0ull) { off = nd_skip; continue; }
+                    off += 32u;
+                    if (nd_leaf >= 0) { leaf = nd_leaf; break; }
+                }
+            } else {
+                float t0, t1, t2, t3, t4, t5;
+                // (wave-uniform by construction; said explicitly for the compiler's divergence analysis)
+                off = (unsigned)__builtin_amdgcn_readfirstlane((int)off);
+                end = (unsigned)__builtin_amdgcn_readfirstlane((int)end);
+                DR_WALK_ASM("s_cmp_lt_u32 %[off], %[end]\n\ts_cbranch_scc0 8f\n\t");
+            }
+            if (leaf == BVH_END) continue;          // range done
+        } else if (roff < rend) {
+            // the records of the current segment, up to the first one some live ray touches
+            int r_hit, r_start, r_end;
+            if (STATS) {
+                r_hit = 0; r_start = 0; r_end = 0;
+                while (roff < rend) {
+                    const v8f raw = *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(rbase) + roff);
+                    const float nc[3] = { raw[0], raw[1], raw[2] }, nh[3] = { raw[3], raw[4], raw[5] };
+                    roff += 32u;
+                    n_stream++;
+                    if ((node_hit_mask(nc, nh, iv, kk, tmax) & alive_m) != 0ull) {
+                        r_hit = 1;
+                        r_start = __builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
+                        r_end = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
+                        break;
+                    }
+                }
+            } else {
+                float t0, t1, t2, t3, t4, t5;
+                DR_STREAM_ASM;
+            }
+            if (!r_hit) continue;                                   // segment exhausted
+            if (r_end < 0) leaf = r_start;                          // a leaf sibling
+            else { off = (unsigned)r_start; end = (unsigned)r_end; continue; }
+        } else {
+            // next segment / the pair's own leaves (every ray is in their boxes: no box test)
+            seg++;
+            if (seg == 0) { rbase = rec_lo; roff = 0u; rend = (unsigned)ell * 32u; continue; }
+            if (seg == 1) { rbase = rec_lo; roff = (unsigned)(ell + 1) * 32u; rend = (unsigned)Dl * 32u; if (roff > rend) roff = rend; continue; }
+            if (seg == 2) { rbase = rec_hi; roff = (unsigned)(ell + 1) * 32u; rend = (unsigned)Dh * 32u; if (roff > rend) roff = rend; continue; }
+            if (seg == 3) leaf = leaf_lo;
+            else if (seg == 4 && leaf_hi != leaf_lo) leaf = leaf_hi;
+            else break;
+        }
+        if (STATS) n_leaf++;
+        const unsigned long long blocked_m = leaf_blocked_mask(tri_sorted, leaf, org, dn, inv, tmax, hi, alive_m);
+        alive_m &= ~blocked_m;
+        if (alive_m == 0ull) break;
+    }
+    return alive_m;
+}
+#undef DR_STREAM_ASM
+#undef DR_WALK_ASM
+#undef DR_NODE_TEST
 
 // ---------------------------------------------------------------------------------------
 // Tile-pair shaft culling.
@@ -772,8 +957,11 @@ __device__ __forceinline__ int build_shaft_list(const BvhNode* __restrict__ bvh,
 // the compiler give up scalar (SMEM) loads for nodes and triangles, so it is a separate,
 // debug-only instantiation.
 // amdgpu_num_sgpr: at most 90 allocatable + 6 (VCC, FLAT_SCRATCH, XNACK) = 96, the most a CU still admits 7 blocks with
-template <int NT, bool STATS, bool SHAFT>
+// WALK: 0 = every pair's walk starts at the root (shipped); 1 = over the tile pair's shaft list (build_shaft_list); 2 = over the
+// two patches' path records (walk_pair).  1 and 2 are exact and measured slower: profiles/r02/assembly_notes.md.
+template <int NT, bool STATS, int WALK>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(98))) void k_ff_tiles(TileParams P) {
+    constexpr bool SHAFT = (WALK == 1), PATHS = (WALK == 2);
     const int t = blockIdx.x;
     const int o = P.tile0 + blockIdx.y;
     const bool t_owned = (t >= P.tile0) && (t < P.tile0 + P.nOwnedTiles);
@@ -899,7 +1087,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(98))) void k_ff_
             const f3 la = ld3(Tl.a), le1 = ld3(Tl.e1), le2 = ld3(Tl.e2);
             const f3 ha = ld3(Th.a), he1 = ld3(Th.e1), he2 = ld3(Th.e2);
             int count = 0;
-            int n_visit = 0, n_leaf = 0;
+            int n_visit = 0, n_leaf = 0, n_stream = 0;
+            // the two patches' path records (PathHdr): where their root-to-leaf paths part, which records to stream
+            int ell = 0, pDl = 0, pDh = 0, leaf_lo = 0, leaf_hi = 0;
+            bool no_paths = true;
+            const BvhNode *rec_lo = nullptr, *rec_hi = nullptr;
+            if (PATHS && P.path_hdr != nullptr) {
+                const PathHdr hl = P.path_hdr[lo], hh = P.path_hdr[hi];
+                const int Dl = __builtin_amdgcn_readfirstlane(hl.depth), Dh = __builtin_amdgcn_readfirstlane(hh.depth);
+                if (Dl >= 0 && Dh >= 0) {
+                    no_paths = false;
+                    const int m = min(Dl, Dh);
+                    const unsigned tl = (unsigned)__builtin_amdgcn_readfirstlane((int)hl.turns), th = (unsigned)__builtin_amdgcn_readfirstlane((int)hh.turns);
+                    const unsigned x = (tl ^ th) & (m >= 32 ? 0xffffffffu : ((1u << m) - 1u));
+                    ell = x ? __builtin_ctz(x) : m;                 // levels the two paths share
+                    pDl = Dl; pDh = Dh;
+                    leaf_lo = __builtin_amdgcn_readfirstlane(hl.leaf); leaf_hi = __builtin_amdgcn_readfirstlane(hh.leaf);
+                    rec_lo = P.path_rec + (size_t)lo * PATH_RECS; rec_hi = P.path_rec + (size_t)hi * PATH_RECS;
+                }
+            }
             for (int k0 = 0; k0 < P.K; k0 += 64) {
                 const int k = k0 + lane;
                 bool alive = k < P.K;
@@ -940,12 +1146,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(98))) void k_ff_
                         from_root = (__builtin_amdgcn_ballot_w64(alive && !inb) != 0ull);
                         if (STATS && from_root && lane == 0 && P.dbg_lo < 0) atomicAdd(P.pairs_traced + 10, 1ull);
                     }
-                    const int ne = from_root ? 1 : n_list;
+                    if (WALK == 0) {
+                        // the whole tree, sentinel-terminated: no end-of-range compares in the walk
+                        alive_m = walk_range<STATS, false>(P.bvh, P.tri_sorted, 0u, end_all, org, dn, inv, iv, kk, tmax, hi, alive_m, n_visit, n_leaf);
+                    }
+                    if (PATHS) {
+                        alive_m = walk_pair<STATS>(P.bvh, P.tri_sorted, rec_lo, rec_hi, ell, pDl, pDh, leaf_lo, leaf_hi, no_paths, end_all,
+                                                   org, dn, inv, iv, kk, tmax, hi, alive_m, n_visit, n_leaf, n_stream);
+                    }
+                    const int ne = !SHAFT ? 0 : (from_root ? 1 : n_list);
                     for (int e = 0; e < ne; e++) {
                         const uint2 rg = sList[e];
                         const unsigned r_off = from_root ? 0u : (unsigned)__builtin_amdgcn_readfirstlane((int)rg.x);
                         const unsigned r_end = from_root ? end_all : (unsigned)__builtin_amdgcn_readfirstlane((int)rg.y);
-                        alive_m = walk_range<STATS, SHAFT>(P.bvh, P.tri_sorted, r_off, r_end, org, dn, inv, iv, kk, tmax, hi, alive_m, n_visit, n_leaf);
+                        alive_m = walk_range<STATS, true>(P.bvh, P.tri_sorted, r_off, r_end, org, dn, inv, iv, kk, tmax, hi, alive_m, n_visit, n_leaf);
                         if (alive_m == 0ull) break;
                     }
                 }
@@ -956,6 +1170,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(98))) void k_ff_
             if (STATS && lane == 0 && P.dbg_lo < 0) {
                 atomicAdd(P.pairs_traced + 1, (unsigned long long)n_visit);
                 atomicAdd(P.pairs_traced + 2, (unsigned long long)n_leaf);
+                atomicAdd(P.pairs_traced + 12, (unsigned long long)n_stream);
             }
         }
     }
@@ -1015,19 +1230,19 @@ static int tile_threads() {
 
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p) {
     dim3 grid(p.nT, p.nOwnedTiles);
+    const int walk = p.shaft ? 1 : (p.path_hdr ? 2 : 0);
     if (p.stats & 1) {
-        if (p.shaft) hipLaunchKernelGGL((k_ff_tiles<256, true, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((k_ff_tiles<256, true, false>), grid, dim3(256), 0, st, p);
+        if (walk == 1) hipLaunchKernelGGL((k_ff_tiles<256, true, 1>), grid, dim3(256), 0, st, p);
+        else if (walk == 2) hipLaunchKernelGGL((k_ff_tiles<256, true, 2>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_ff_tiles<256, true, 0>), grid, dim3(256), 0, st, p);
         return hipGetLastError();
     }
-    if (p.shaft) {
-        hipLaunchKernelGGL((k_ff_tiles<256, false, true>), grid, dim3(256), 0, st, p);
-        return hipGetLastError();
-    }
+    if (walk == 1) { hipLaunchKernelGGL((k_ff_tiles<256, false, 1>), grid, dim3(256), 0, st, p); return hipGetLastError(); }
+    if (walk == 2) { hipLaunchKernelGGL((k_ff_tiles<256, false, 2>), grid, dim3(256), 0, st, p); return hipGetLastError(); }
     switch (tile_threads()) {
-        case 512: hipLaunchKernelGGL((k_ff_tiles<512, false, false>), grid, dim3(512), 0, st, p); break;
-        case 1024: hipLaunchKernelGGL((k_ff_tiles<1024, false, false>), grid, dim3(1024), 0, st, p); break;
-        default: hipLaunchKernelGGL((k_ff_tiles<256, false, false>), grid, dim3(256), 0, st, p); break;
+        case 512: hipLaunchKernelGGL((k_ff_tiles<512, false, 0>), grid, dim3(512), 0, st, p); break;
+        case 1024: hipLaunchKernelGGL((k_ff_tiles<1024, false, 0>), grid, dim3(1024), 0, st, p); break;
+        default: hipLaunchKernelGGL((k_ff_tiles<256, false, 0>), grid, dim3(256), 0, st, p); break;
     }
     return hipGetLastError();
 }
