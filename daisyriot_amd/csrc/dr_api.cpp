@@ -214,7 +214,7 @@ int sweep_once(dr_context* c, int conv_mode = 0, float thr = 0.0f) {
     p.ldF = c->ldF; p.F = c->d_F; p.Rin = c->d_R[c->cur]; p.Rout = c->d_R[c->cur ^ 1]; p.rank = c->rank;
     p.cstride = c->cstride;
     p.B = c->d_B; p.M = c->d_M; p.mat = c->d_mat; p.n_mat = c->n_mat;
-    p.skew = 0; p.ksplit = c->ksplit; p.Gpart = c->d_Gpart;
+    p.skew = 0; p.taper = 0; p.ksplit = c->ksplit; p.Gpart = c->d_Gpart;
     p.tickets = c->d_tickets; p.blk_sums = c->d_blk_sums; p.ctl = c->d_ctl; p.conv_mode = conv_mode; p.conv_thr = thr;
     // plain passes (dr_solver_step) do not form the sums; whoever asks for them afterwards gets them from k_chunk_sums
     p.want_sums = conv_mode != 0 ? 1 : 0;

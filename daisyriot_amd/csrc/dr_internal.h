@@ -128,6 +128,8 @@ struct SweepParams {
     const int* mat;       // [rpr] local material index
     int n_mat;
     int skew;         // per-block start-tile multiplier (0 = every block starts at column 0)
+    int taper;        // column ranges of decreasing size (the later a block is dispatched, the less it has to do): range y gets a share
+                      // proportional to taper + gridDim.y - y; 0 = equal ranges
     int ksplit;       // column ranges (gridDim.y); > 1: partial sums to Gpart, the last range of a row block to finish adds them up
     float* Gpart;     // [ksplit][nrows][S] partial F*R sums when ksplit > 1
     // in-launch reductions: [0] counts the row blocks whose epilogue is done (the last one adds up blk_sums into the

@@ -39,6 +39,17 @@ __device__ __forceinline__ bool residual_converged(const SweepParams& P) {
     return P.conv_mode == 2 ? !any : !(tot > (double)P.conv_thr);
 }
 
+// first tile of column range y of n: equal ranges (taper 0), or shares proportional to taper + n - y (blocks are dispatched in
+// the order of y: the last ones to start are the shortest, which evens out when the slots of the chip finish)
+__device__ __forceinline__ int range_start(int y, int n, int ntiles, int taper) {
+    if (taper == 0) return (int)(((long long)y * ntiles) / n);
+    if (taper < 0) taper = 0;          // the steepest: shares n, n-1, .., 1
+    // sum_{k<y} (taper + n - k) = y*(taper + n) - y*(y-1)/2
+    const long long tot = (long long)n * (taper + n) - (long long)n * (n - 1) / 2;
+    const long long acc = (long long)y * (taper + n) - (long long)y * (y - 1) / 2;
+    return (int)((acc * ntiles) / tot);
+}
+
 // Hand-off between the blocks of one launch without fences (MI355X_MICROARCH.md, "Workgroup dispatch ... inter-workgroup
 // visibility", the table of hand-offs with sc1 loads in place of the acquire, first row): every byte that another block
 // will read is stored write-through (relaxed agent-scope store = global_store ... sc1) and read with sc1 loads
@@ -163,8 +174,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
     const int rbase = (blockIdx.x * NW + wave) * RR;       // first local row of this wave (uniform)
     const int ntiles_all = (P.world * P.rpr) / TC;
     // tiles of this block: the column ranges need not be equal, they only have to cover every tile once
-    const int tile0 = SPLIT ? (int)(((long long)blockIdx.y * ntiles_all) / (int)gridDim.y) : 0;
-    const int ntiles = SPLIT ? (int)(((long long)(blockIdx.y + 1) * ntiles_all) / (int)gridDim.y) - tile0 : ntiles_all;
+    const int tile0 = SPLIT ? range_start(blockIdx.y, gridDim.y, ntiles_all, P.taper) : 0;
+    const int ntiles = SPLIT ? range_start(blockIdx.y + 1, gridDim.y, ntiles_all, P.taper) - tile0 : ntiles_all;
     const int tiles_per_chunk = P.rpr / TC;
 
     // wave-uniform row bases (SGPRs); rows past the shard are clamped for loading, masked at the end
@@ -353,8 +364,8 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_mfma(SweepParams P) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rbase = (blockIdx.x * NW + wave) * MT_ROWS;
     const int ntiles_all = (P.world * P.rpr) / MT_TC;
-    const int tile0 = SPLIT ? (int)(((long long)blockIdx.y * ntiles_all) / (int)gridDim.y) : 0;
-    const int ntiles = SPLIT ? (int)(((long long)(blockIdx.y + 1) * ntiles_all) / (int)gridDim.y) - tile0 : ntiles_all;
+    const int tile0 = SPLIT ? range_start(blockIdx.y, gridDim.y, ntiles_all, P.taper) : 0;
+    const int ntiles = SPLIT ? range_start(blockIdx.y + 1, gridDim.y, ntiles_all, P.taper) - tile0 : ntiles_all;
     const int tiles_per_chunk = P.rpr / MT_TC;
 
     // bins S..15 of the residual tile are zero and never rewritten
@@ -569,6 +580,10 @@ hipError_t launch_sweep(hipStream_t st, const SweepParams& p_in) {
     const int skew = skew_env >= 0 ? skew_env : (residual_bytes <= ((size_t)5 << 19) ? 37 : 0);
     if (mfma < 0) { const char* e = getenv("DR_SWEEP_MFMA"); mfma = e ? atoi(e) : 1; }
     p.skew = skew;
+    // column ranges of decreasing size (shares n, n-1, .., 1) when the columns are cut at all: the blocks dispatched last are the
+    // shortest, which trims the drain of a small shard's pass (8192 rows of the 64k problem, 4 ranges: 0.348 -> 0.333 ms;
+    // profiles/r02/sweep_shards.md).  DR_SWEEP_TAPER: 0 = equal ranges, t > 0 = shares t + n - y
+    { static int tp = -2; if (tp == -2) { const char* e = getenv("DR_SWEEP_TAPER"); tp = e ? atoi(e) : -1; } p.taper = p.ksplit > 1 ? tp : 0; }
     if (p.S > 8 && mfma) return launch_sweep_mfma(st, p);
     switch (p.S) {
 #define DR_CASE(n) case n: return launch_sweep_s<n>(st, p);
