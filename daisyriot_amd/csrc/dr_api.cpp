@@ -485,7 +485,6 @@ static int assemble_launch(dr_context* c, int K, float eps, int rule, int trace,
         // tile-pair shaft culling (geom_kernels.hip), off unless DR_SHAFT=1: exact, but measured slower than walks from
         // the root (profiles/r02/assembly_notes.md); DR_SHAFT_MIN = nodes below which a subtree is listed whole
         { const char* e = getenv("DR_SHAFT"); p.shaft = e ? atoi(e) : 0; }
-        { const char* e = getenv("DR_WALK2"); if (e && atoi(e)) p.shaft = 3; }       // two pairs per walk (experiment)
         { const char* e = getenv("DR_SHAFT_MIN"); p.shaft_min_bytes = (e ? atoi(e) : 128) * (int)sizeof(BvhNode); }
         { const char* e = getenv("DR_SHAFT_SHRINK"); p.shaft_near_shrink = e ? (float)atof(e) : 0.25f; }
         p.shaft_pad_ray = 1e-6f * c->scene_span; p.shaft_pad_node = 5e-6f * c->scene_span; p.shaft_tol = c->scene_span;

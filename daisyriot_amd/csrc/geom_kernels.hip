@@ -816,141 +816,6 @@ __device__ __forceinline__ unsigned long long walk_pair(const BvhNode* __restric
 #undef DR_WALK_ASM
 #undef DR_NODE_TEST
 
-// ---- TWO pairs per walk (WALK == 3) --------------------------------------------------------------------------------
-// A pair's walk is a chain of dependent node fetches, about one L2 round trip per node, and the hardware's 8 waves per SIMD
-// do not hide it (profiles/r02/assembly_notes.md).  Queue neighbours are almost always (lo, hi) and (lo, hi + 1) -- the same
-// source patch, the two halves of one quad as destinations: their rays run side by side.  Here one wave carries BOTH pairs,
-// two rays per lane, through ONE walk: a node is entered when a live ray of either pair touches it, every fetch, scalar
-// instruction and leaf record load is shared, only the vector tests are made twice.  Each ray is still tested against
-// every triangle of every leaf the walk reaches with its own (org, dn, tmax, hi): a superset of the leaves its own walk
-// would reach -- exact.
-struct RaySet { f3 org, dn, inv, iv, kk; float tmax; };
-
-#define DR_NODE_TEST_N(CX, CY, CZ, HX, HY, HZ, N)                                         \
-                "v_fma_f32 %[t0], " CX ", %[ix" N "], %[kx" N "]\n\t"                     \
-                "v_fma_f32 %[t1], " CY ", %[iy" N "], %[ky" N "]\n\t"                     \
-                "v_fma_f32 %[t2], " CZ ", %[iz" N "], %[kz" N "]\n\t"                     \
-                "v_fma_f32 %[t3], " HX ", -|%[ix" N "]|, %[t0]\n\t"                       \
-                "v_fma_f32 %[t0], " HX ", |%[ix" N "]|, %[t0]\n\t"                        \
-                "v_fma_f32 %[t4], " HY ", -|%[iy" N "]|, %[t1]\n\t"                       \
-                "v_fma_f32 %[t1], " HY ", |%[iy" N "]|, %[t1]\n\t"                        \
-                "v_fma_f32 %[t5], " HZ ", -|%[iz" N "]|, %[t2]\n\t"                       \
-                "v_fma_f32 %[t2], " HZ ", |%[iz" N "]|, %[t2]\n\t"                        \
-                "v_max3_f32 %[t3], %[t3], %[t4], %[t5]\n\t"                               \
-                "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t"                               \
-                "v_max_f32_e32 %[t3], 0, %[t3]\n\t"                                       \
-                "v_min_f32_e32 %[t0], %[t0], %[tmax" N "]\n\t"                            \
-                "v_cmp_le_f32_e32 vcc, %[t3], %[t0]\n\t"
-// both ray sets against one node: scc = some live ray of either touches it
-#define DR_NODE_TEST_2(CX, CY, CZ, HX, HY, HZ)                                            \
-                DR_NODE_TEST_N(CX, CY, CZ, HX, HY, HZ, "1")                               \
-                "s_and_b64 %[m1], vcc, %[alive1]\n\t"                                     \
-                DR_NODE_TEST_N(CX, CY, CZ, HX, HY, HZ, "2")                               \
-                "s_and_b64 vcc, vcc, %[alive2]\n\t"                                       \
-                "s_or_b64 vcc, vcc, %[m1]\n\t"
-
-template <bool STATS>
-__device__ __forceinline__ void walk_root_2(const BvhNode* __restrict__ bvh, const TriRec* __restrict__ tri_sorted, const RaySet& r1,
-                                            const RaySet& r2, int hi1, int hi2, unsigned long long& alive1, unsigned long long& alive2,
-                                            int& n_visit, int& n_leaf) {
-    if ((alive1 | alive2) == 0ull) return;
-    unsigned off = 0u;
-    for (;;) {
-        int leaf;
-        if (STATS) {
-            for (;;) {
-                const v8f raw = *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(bvh) + off);
-                const float nc[3] = { raw[0], raw[1], raw[2] }, nh[3] = { raw[3], raw[4], raw[5] };
-                const unsigned nd_skip = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
-                leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
-                n_visit++;
-                const unsigned long long hb = (node_hit_mask(nc, nh, r1.iv, r1.kk, r1.tmax) & alive1) | (node_hit_mask(nc, nh, r2.iv, r2.kk, r2.tmax) & alive2);
-                if (hb == 0ull) { off = nd_skip; continue; }
-                off += 32u;
-                if (leaf >= 0) break;
-            }
-        } else {
-            float t0, t1, t2, t3, t4, t5;
-            unsigned long long m1;
-            asm volatile(
-                "s_load_dwordx8 " DR_A_ALL ", %[bvh], %[off] offset:0x0\n\t"
-                "s_waitcnt lgkmcnt(0)\n"
-                "1:\n\t"
-                "s_load_dwordx8 " DR_B_ALL ", %[bvh], %[off] offset:0x20\n\t"
-                DR_NODE_TEST_2(DR_A0, DR_A1, DR_A2, DR_A3, DR_A4, DR_A5)
-                "s_cbranch_scc0 3f\n\t"
-                "s_add_u32 %[off], %[off], 32\n\t"
-                "s_cmp_lt_i32 " DR_A7 ", 0\n\t"
-                "s_cbranch_scc0 5f\n\t"
-                "s_waitcnt lgkmcnt(0)\n"
-                "2:\n\t"
-                "s_load_dwordx8 " DR_A_ALL ", %[bvh], %[off] offset:0x20\n\t"
-                DR_NODE_TEST_2(DR_B0, DR_B1, DR_B2, DR_B3, DR_B4, DR_B5)
-                "s_cbranch_scc0 4f\n\t"
-                "s_add_u32 %[off], %[off], 32\n\t"
-                "s_cmp_lt_i32 " DR_B7 ", 0\n\t"
-                "s_cbranch_scc0 6f\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "s_branch 1b\n"
-                "3:\n\t"
-                "s_mov_b32 %[off], " DR_A6 "\n\t"
-                "s_load_dwordx8 " DR_A_ALL ", %[bvh], %[off] offset:0x0\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "s_branch 1b\n"
-                "4:\n\t"
-                "s_mov_b32 %[off], " DR_B6 "\n\t"
-                "s_load_dwordx8 " DR_B_ALL ", %[bvh], %[off] offset:0x0\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "s_branch 2b\n"
-                "5:\n\t"
-                "s_mov_b32 %[leaf], " DR_A7 "\n\t"
-                "s_branch 7f\n"
-                "6:\n\t"
-                "s_mov_b32 %[leaf], " DR_B7 "\n"
-                "7:\n\t"
-                "s_waitcnt lgkmcnt(0)"
-                : [off] "+s"(off), [leaf] "=s"(leaf), [m1] "=&s"(m1), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
-                  [t4] "=&v"(t4), [t5] "=&v"(t5)
-                : [bvh] "s"(bvh), [alive1] "s"(alive1), [alive2] "s"(alive2),
-                  [kx1] "v"(r1.kk.x), [ky1] "v"(r1.kk.y), [kz1] "v"(r1.kk.z), [ix1] "v"(r1.iv.x), [iy1] "v"(r1.iv.y), [iz1] "v"(r1.iv.z), [tmax1] "v"(r1.tmax),
-                  [kx2] "v"(r2.kk.x), [ky2] "v"(r2.kk.y), [kz2] "v"(r2.kk.z), [ix2] "v"(r2.iv.x), [iy2] "v"(r2.iv.y), [iz2] "v"(r2.iv.z), [tmax2] "v"(r2.tmax)
-                : DR_WALK_CLOBBERS, "vcc", "scc");
-        }
-        if (leaf == BVH_END) break;          // the tree's sentinel
-        if (STATS) n_leaf++;
-        // the leaf's triangles against both ray sets (each with its own destination)
-        if (alive1 != 0ull) alive1 &= ~leaf_blocked_mask(tri_sorted, leaf, r1.org, r1.dn, r1.inv, r1.tmax, hi1, alive1);
-        if (alive2 != 0ull) alive2 &= ~leaf_blocked_mask(tri_sorted, leaf, r2.org, r2.dn, r2.inv, r2.tmax, hi2, alive2);
-        if ((alive1 | alive2) == 0ull) break;
-    }
-}
-#undef DR_NODE_TEST_2
-#undef DR_NODE_TEST_N
-
-// the k-th ray of the pair (lo -> hi): uv2xyz on both patches (vs/triangle_math.cpp:3-9), ray per
-// vs/OptixPrimeFunctionality.cpp:191-196, then "the destination must be hit at all" (its gate on [0,inf) and the triangle test)
-__device__ __forceinline__ bool make_ray(const TriRec& Tl, const TriRec& Th, const float* __restrict__ uv, int k, int K, float eps, int lane, RaySet& r) {
-    bool alive = k < K;
-    r.org = f3{ 0, 0, 0 }; r.dn = f3{ 0, 0, 1 }; r.tmax = 0.0f;
-    const f3 ha = ld3(Th.a), he1 = ld3(Th.e1), he2 = ld3(Th.e2);
-    if (alive) {
-        const f3 la = ld3(Tl.a), le1 = ld3(Tl.e1), le2 = ld3(Tl.e2);
-        const float u = uv[2 * k], v = uv[2 * k + 1];
-        f3 src = (la + le1 * u) + le2 * v;
-        f3 dst = (ha + he1 * u) + he2 * v;
-        f3 dv = dst - src;
-        r.dn = dv * (1.0f / sqrtf(dot3(dv, dv)));
-        r.org = src + r.dn * eps;
-    }
-    r.inv = f3{ safe_inv(r.dn.x), safe_inv(r.dn.y), safe_inv(r.dn.z) };
-    if (alive) alive = tri_hit(r.org, r.dn, ha, he1, he2, r.tmax);
-    alive = alive && ((box_hit_mask(Th.lo, Th.hi, r.org, r.inv, INFINITY) >> lane) & 1ull);
-    r.iv = f3{ __builtin_amdgcn_fmed3f(r.inv.x, -1e18f, 1e18f), __builtin_amdgcn_fmed3f(r.inv.y, -1e18f, 1e18f),
-               __builtin_amdgcn_fmed3f(r.inv.z, -1e18f, 1e18f) };
-    r.kk = f3{ -(r.org.x * r.iv.x), -(r.org.y * r.iv.y), -(r.org.z * r.iv.z) };
-    return alive;
-}
-
 // ---------------------------------------------------------------------------------------
 // Tile-pair shaft culling.
 //
@@ -1213,33 +1078,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(98))) void k_ff_
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int n_act_u = __builtin_amdgcn_readfirstlane(n_act);
         const int n_list = use_shaft ? __builtin_amdgcn_readfirstlane(sNList) : 1;
-        if (WALK == 3) {
-            // two queue neighbours per wave and walk (see walk_root_2)
-            for (int q = 2 * wave; q < n_act_u; q += 2 * (NT / 64)) {
-                const bool two = (q + 1) < n_act_u;
-                const int p1 = __builtin_amdgcn_readfirstlane((int)sQueue[q]);
-                const int p2 = two ? __builtin_amdgcn_readfirstlane((int)sQueue[q + 1]) : p1;
-                const int i1 = p1 >> 6, j1 = p1 & 63, i2 = p2 >> 6, j2 = p2 & 63;
-                const int lo1 = I0 + i1, hi1 = J0 + j1, lo2 = I0 + i2, hi2 = J0 + j2;
-                int count1 = 0, count2 = 0, n_visit = 0, n_leaf = 0;
-                for (int k0 = 0; k0 < P.K; k0 += 64) {
-                    // (the patches' records are fetched per chunk of 64 rays -- once, for K <= 64 -- so that nothing of them has
-                    // to live across the walk)
-                    RaySet r1, r2;
-                    const bool a1 = make_ray(P.tri[lo1], P.tri[hi1], P.uv, k0 + lane, P.K, P.eps, lane, r1);
-                    const bool a2 = make_ray(P.tri[lo2], P.tri[hi2], P.uv, k0 + lane, two ? P.K : 0, P.eps, lane, r2);
-                    unsigned long long m1 = __builtin_amdgcn_ballot_w64(a1), m2 = __builtin_amdgcn_ballot_w64(a2);
-                    walk_root_2<STATS>(P.bvh, P.tri_sorted, r1, r2, hi1, hi2, m1, m2, n_visit, n_leaf);
-                    count1 += __popcll(m1); count2 += __popcll(m2);
-                }
-                if (lane == 0) { sVis[i1][j1] = (unsigned char)count1; if (two) sVis[i2][j2] = (unsigned char)count2; }
-                if (STATS && lane == 0 && P.dbg_lo < 0) {
-                    atomicAdd(P.pairs_traced + 1, (unsigned long long)n_visit);
-                    atomicAdd(P.pairs_traced + 2, (unsigned long long)n_leaf);
-                }
-            }
-        }
-        for (int q = wave; WALK != 3 && q < n_act_u; q += NT / 64) {
+        for (int q = wave; q < n_act_u; q += NT / 64) {
             const int p = __builtin_amdgcn_readfirstlane((int)sQueue[q]);
             const int i = p >> 6, j = p & 63;
             const int lo = I0 + i, hi = J0 + j;
@@ -1391,17 +1230,15 @@ static int tile_threads() {
 
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p) {
     dim3 grid(p.nT, p.nOwnedTiles);
-    const int walk = p.shaft == 3 ? 3 : (p.shaft ? 1 : (p.path_hdr ? 2 : 0));
+    const int walk = p.shaft ? 1 : (p.path_hdr ? 2 : 0);
     if (p.stats & 1) {
         if (walk == 1) hipLaunchKernelGGL((k_ff_tiles<256, true, 1>), grid, dim3(256), 0, st, p);
         else if (walk == 2) hipLaunchKernelGGL((k_ff_tiles<256, true, 2>), grid, dim3(256), 0, st, p);
-        else if (walk == 3) hipLaunchKernelGGL((k_ff_tiles<256, true, 3>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((k_ff_tiles<256, true, 0>), grid, dim3(256), 0, st, p);
         return hipGetLastError();
     }
     if (walk == 1) { hipLaunchKernelGGL((k_ff_tiles<256, false, 1>), grid, dim3(256), 0, st, p); return hipGetLastError(); }
     if (walk == 2) { hipLaunchKernelGGL((k_ff_tiles<256, false, 2>), grid, dim3(256), 0, st, p); return hipGetLastError(); }
-    if (walk == 3) { hipLaunchKernelGGL((k_ff_tiles<256, false, 3>), grid, dim3(256), 0, st, p); return hipGetLastError(); }
     switch (tile_threads()) {
         case 512: hipLaunchKernelGGL((k_ff_tiles<512, false, 0>), grid, dim3(512), 0, st, p); break;
         case 1024: hipLaunchKernelGGL((k_ff_tiles<1024, false, 0>), grid, dim3(1024), 0, st, p); break;
