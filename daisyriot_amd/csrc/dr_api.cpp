@@ -60,6 +60,7 @@ struct dr_context {
     PatchRec* d_patch = nullptr;
     TriRec *d_tri = nullptr, *d_tri_sorted = nullptr;
     BvhNode* d_bvh = nullptr;
+    BvhNode* d_bvh_lh = nullptr;      // the nodes as lower / upper corners (sign-specialised node test)
     BvhNode* d_path_rec = nullptr;    // [N][PATH_RECS] path records of the patches (PathHdr, dr_internal.h)
     PathHdr* d_path_hdr = nullptr;
     int n_nodes = 0;
@@ -139,6 +140,7 @@ void free_scene(dr_context* c) {
     hipFree(c->d_vtx); hipFree(c->d_nrm); hipFree(c->d_tv); hipFree(c->d_tn);
     hipFree(c->d_patch); hipFree(c->d_tri); hipFree(c->d_tri_sorted); hipFree(c->d_bvh);
     hipFree(c->d_path_rec); hipFree(c->d_path_hdr); c->d_path_rec = nullptr; c->d_path_hdr = nullptr;
+    hipFree(c->d_bvh_lh); c->d_bvh_lh = nullptr;
     c->d_vtx = c->d_nrm = nullptr; c->d_tv = c->d_tn = nullptr;
     c->d_patch = nullptr; c->d_tri = nullptr; c->d_tri_sorted = nullptr; c->d_bvh = nullptr; c->N = 0;
 }
@@ -398,6 +400,7 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     HIPCHK(hipMalloc(&c->d_tri_sorted, sizeof(TriRec) * ((size_t)N + LEAF_MAX)));
     c->n_nodes = 2 * N - 1;
     HIPCHK(hipMalloc(&c->d_bvh, sizeof(BvhNode) * ((size_t)c->n_nodes + 2)));     // + the sentinel + one node the walk's prefetch may touch
+    HIPCHK(hipMalloc(&c->d_bvh_lh, sizeof(BvhNode) * ((size_t)c->n_nodes + 2)));
     HIPCHK(hipMalloc(&c->d_path_rec, sizeof(BvhNode) * (size_t)N * PATH_RECS));
     HIPCHK(hipMalloc(&c->d_path_hdr, sizeof(PathHdr) * (size_t)N));
     HIPCHK(hipMemcpyAsync(c->d_vtx, vertices, sizeof(float) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream));
@@ -408,7 +411,7 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     EventPair ev;
     HIPCHK(ev.create());
     HIPCHK(hipEventRecord(ev.a, c->stream));
-    hipError_t be = build_lbvh(c->stream, N, c->d_tri, lo, hi, node_pad, c->d_bvh, c->d_tri_sorted, &c->n_nodes, c->d_path_rec, c->d_path_hdr);
+    hipError_t be = build_lbvh(c->stream, N, c->d_tri, lo, hi, node_pad, c->d_bvh, c->d_bvh_lh, c->d_tri_sorted, &c->n_nodes, c->d_path_rec, c->d_path_hdr);
     if (be != hipSuccess) return fail(DR_ERR_DEVICE, "LBVH build failed: %s", hipGetErrorString(be));
     HIPCHK(hipEventRecord(ev.b, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -478,6 +481,8 @@ static int assemble_launch(dr_context* c, int K, float eps, int rule, int trace,
         p.row0 = c->row0; p.nrows = c->nrows; p.n_nodes = c->n_nodes; p.eps = eps; p.ldF = c->ldF;
         p.F = c->d_F; p.vis = c->d_vis; p.patch = c->d_patch; p.tri = c->d_tri; p.tri_sorted = c->d_tri_sorted; p.bvh = c->d_bvh;
         p.uv = c->d_uv; p.pairs_traced = c->d_counter;
+        // DR_OCTANT=0: the general node test for every pair (A/B runs)
+        { const char* e = getenv("DR_OCTANT"); p.bvh_lh = (e && !atoi(e)) ? nullptr : c->d_bvh_lh; }
         // DR_PATHS=1: the pairs' walks run over the two patches' path records instead of starting at the root (exact, measured
         // slower: profiles/r02/assembly_notes.md)
         { const char* e = getenv("DR_PATHS"); const bool on = e ? atoi(e) != 0 : false; p.path_rec = on ? c->d_path_rec : nullptr; p.path_hdr = on ? c->d_path_hdr : nullptr; }

@@ -73,6 +73,7 @@ struct TileParams {
     const TriRec* tri;          // original order (ray generation)
     const TriRec* tri_sorted;   // Morton order, LEAF_MAX never-hit padding records at the end (leaf tests)
     const BvhNode* bvh;
+    const BvhNode* bvh_lh;      // the same nodes with c[] = lower, h[] = upper corner (sign-specialised node test); null: not used
     const BvhNode* path_rec;    // [N][PATH_RECS] path records (see PathHdr); null: every walk starts at the root
     const PathHdr* path_hdr;    // [N]
     const float* uv;          // K x 2
@@ -154,6 +155,7 @@ hipError_t launch_patch_records(hipStream_t st, int N, const float* vtx, const f
                                 const int* tv, const int* tn, float box_pad, PatchRec* patch, TriRec* tri);
 hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float scene_lo[3],
                       const float scene_hi[3], float node_pad, BvhNode* nodes /* room for 2N */,
+                      BvhNode* nodes_lh /* the same in lower / upper corner form */,
                       TriRec* tri_sorted /* N + LEAF_MAX */, int* n_nodes_out,
                       BvhNode* path_rec /* N * PATH_RECS */, PathHdr* path_hdr /* N */);
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p);

@@ -218,7 +218,7 @@ __global__ void k_refit(int N, const TriRec* __restrict__ tri, const int* __rest
 __global__ void k_emit(int N, const int* __restrict__ left, const int* __restrict__ first,
                        const int* __restrict__ last, const int* __restrict__ parent,
                        const float* __restrict__ box, const int* __restrict__ esize, float node_pad,
-                       const TriRec* __restrict__ tri_sorted, BvhNode* __restrict__ nodes,
+                       const TriRec* __restrict__ tri_sorted, BvhNode* __restrict__ nodes, BvhNode* __restrict__ nodes_lh,
                        int* __restrict__ pre /* 2N-1, preset to -1: pre-order index of every node that is written */) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= 2 * N - 1) return;
@@ -253,6 +253,15 @@ __global__ void k_emit(int N, const int* __restrict__ left, const int* __restric
         if (same) nd.tri |= 4;
     }
     nodes[idx] = nd;
+    // the same node as lower / upper corner (c[] = lo, h[] = hi) for the sign-specialised node test (DR_NODE_TEST_S): a box that
+    // holds [c - h, c + h] whatever the roundings of the two operations below
+    BvhNode lh = nd;
+    for (int a = 0; a < 3; a++) {
+        const float m = 4e-7f * (fabsf(nd.c[a]) + nd.h[a]);
+        lh.c[a] = (nd.c[a] - nd.h[a]) - m;
+        lh.h[a] = (nd.c[a] + nd.h[a]) + m;
+    }
+    nodes_lh[idx] = lh;
     pre[id] = idx;
 }
 
@@ -300,7 +309,7 @@ __global__ void k_pad_tris(int N, TriRec* __restrict__ tri_sorted) {
 }
 
 hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[3], const float shi[3], float node_pad,
-                      BvhNode* nodes, TriRec* tri_sorted, int* n_nodes_out, BvhNode* path_rec, PathHdr* path_hdr) {
+                      BvhNode* nodes, BvhNode* nodes_lh, TriRec* tri_sorted, int* n_nodes_out, BvhNode* path_rec, PathHdr* path_hdr) {
     hipError_t e;
     unsigned long long *keys = nullptr, *keys2 = nullptr;
     int *vals = nullptr, *vals2 = nullptr, *ibuf = nullptr;
@@ -343,7 +352,7 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
         hipLaunchKernelGGL(k_pad_tris, dim3(1), dim3(64), 0, st, N, tri_sorted);
         DR_TRY(hipGetLastError());
         DR_TRY(hipMemsetAsync(pre, 0xff, sizeof(int) * nn, st));
-        hipLaunchKernelGGL(k_emit, dim3((int)((nn + 255) / 256)), dim3(256), 0, st, N, left, first, last, parent, box, esize, node_pad, tri_sorted, nodes, pre);
+        hipLaunchKernelGGL(k_emit, dim3((int)((nn + 255) / 256)), dim3(256), 0, st, N, left, first, last, parent, box, esize, node_pad, tri_sorted, nodes, nodes_lh, pre);
         DR_TRY(hipGetLastError());
         if (path_rec && path_hdr) {
             hipLaunchKernelGGL(k_paths, dim3(nb), dim3(256), 0, st, N, pos, left, right, parent, pre, nodes, path_rec, path_hdr);
@@ -359,6 +368,9 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
         endn.skip = (*n_nodes_out + 1) * (int)sizeof(BvhNode);
         endn.tri = BVH_END;
         DR_TRY(hipMemcpyAsync(nodes + *n_nodes_out, &endn, sizeof(BvhNode), hipMemcpyHostToDevice, st));
+        DR_TRY(hipStreamSynchronize(st));
+        for (int a = 0; a < 3; a++) { endn.c[a] = -INFINITY; endn.h[a] = INFINITY; }          // lo / hi form
+        DR_TRY(hipMemcpyAsync(nodes_lh + *n_nodes_out, &endn, sizeof(BvhNode), hipMemcpyHostToDevice, st));
         DR_TRY(hipStreamSynchronize(st));
     }
 #undef DR_TRY
@@ -576,6 +588,116 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
                 "v_min_f32_e32 %[t0], %[t0], %[tmax]\n\t"                     \
                 "v_cmp_le_f32_e32 vcc, %[t3], %[t0]\n\t"                      \
                 "s_and_b64 vcc, vcc, %[alive]\n\t"
+// The same test when all live rays of the wave point into one octant (a pair's 50 rays nearly always do): with the node
+// as lower / upper corner (bvh_lh) the near and far plane of every axis are known by name, 6 fused multiply-adds
+// instead of 9: tn = fma(near, iv, k), tf = fma(far, iv, k) per axis, accept iff max(tn, 0) <= min(tf, tmax).  Same
+// rounding budget as above (two roundings of (|plane| + |org|)|iv| each), same grown boxes: conservative.
+// N?/F? = the registers that hold the near / far corner's coordinates for the wave's sign pattern.
+#define DR_NODE_TEST_S(NX, NY, NZ, FX, FY, FZ)                                \
+                "v_fma_f32 %[t3], " NX ", %[ix], %[kx]\n\t"                   \
+                "v_fma_f32 %[t4], " NY ", %[iy], %[ky]\n\t"                   \
+                "v_fma_f32 %[t5], " NZ ", %[iz], %[kz]\n\t"                   \
+                "v_fma_f32 %[t0], " FX ", %[ix], %[kx]\n\t"                   \
+                "v_fma_f32 %[t1], " FY ", %[iy], %[ky]\n\t"                   \
+                "v_fma_f32 %[t2], " FZ ", %[iz], %[kz]\n\t"                   \
+                "v_max3_f32 %[t3], %[t3], %[t4], %[t5]\n\t"                   \
+                "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t"                   \
+                "v_max_f32_e32 %[t3], 0, %[t3]\n\t"                           \
+                "v_min_f32_e32 %[t0], %[t0], %[tmax]\n\t"                     \
+                "v_cmp_le_f32_e32 vcc, %[t3], %[t0]\n\t"                      \
+                "s_and_b64 vcc, vcc, %[alive]\n\t"
+// The sentinel-terminated walk from the root in nine variants inside ONE asm statement (one set of operands, no control
+// flow for the compiler to reason about): V = 0..7 the sign-specialised test on bvh_lh for that octant (bit a of V set:
+// the rays point towards -axis a, the near corner's coordinate a is the upper one), "8" the general test on bvh.  Local
+// labels are V followed by 1..7.  The statement starts with a three-level bit test of %[oct] that jumps to the variant.
+#define DR_SEL(S, LO, HI) DR_SEL_##S(LO, HI)
+#define DR_SEL_0(LO, HI) LO
+#define DR_SEL_1(LO, HI) HI
+#define DR_WALK_VARIANT(V, BVH, TESTA, TESTB)                                                                           \
+                V "0:\n\t"                                                                                              \
+                "s_load_dwordx8 " DR_A_ALL ", " BVH ", %[off] offset:0x0\n\t"                                           \
+                "s_waitcnt lgkmcnt(0)\n"                                                                                \
+                V "1:\n\t"                                                                                              \
+                "s_load_dwordx8 " DR_B_ALL ", " BVH ", %[off] offset:0x20\n\t"                                          \
+                TESTA                                                                                                   \
+                "s_cbranch_scc0 " V "3f\n\t"                                                                            \
+                "s_add_u32 %[off], %[off], 32\n\t"                                                                      \
+                "s_cmp_lt_i32 " DR_A7 ", 0\n\t"                                                                         \
+                "s_cbranch_scc0 " V "5f\n\t"                                                                            \
+                "s_waitcnt lgkmcnt(0)\n"                                                                                \
+                V "2:\n\t"                                                                                              \
+                "s_load_dwordx8 " DR_A_ALL ", " BVH ", %[off] offset:0x20\n\t"                                          \
+                TESTB                                                                                                   \
+                "s_cbranch_scc0 " V "4f\n\t"                                                                            \
+                "s_add_u32 %[off], %[off], 32\n\t"                                                                      \
+                "s_cmp_lt_i32 " DR_B7 ", 0\n\t"                                                                         \
+                "s_cbranch_scc0 " V "6f\n\t"                                                                            \
+                "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+                "s_branch " V "1b\n"                                                                                    \
+                V "3:\n\t"                                                                                              \
+                "s_mov_b32 %[off], " DR_A6 "\n\t"                                                                       \
+                "s_load_dwordx8 " DR_A_ALL ", " BVH ", %[off] offset:0x0\n\t"                                           \
+                "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+                "s_branch " V "1b\n"                                                                                    \
+                V "4:\n\t"                                                                                              \
+                "s_mov_b32 %[off], " DR_B6 "\n\t"                                                                       \
+                "s_load_dwordx8 " DR_B_ALL ", " BVH ", %[off] offset:0x0\n\t"                                           \
+                "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+                "s_branch " V "2b\n"                                                                                    \
+                V "5:\n\t"                                                                                              \
+                "s_mov_b32 %[leaf], " DR_A7 "\n\t"                                                                      \
+                "s_branch 99f\n"                                                                                        \
+                V "6:\n\t"                                                                                              \
+                "s_mov_b32 %[leaf], " DR_B7 "\n\t"                                                                      \
+                "s_branch 99f\n"
+#define DR_WALK_OCTANT(V, SX, SY, SZ)                                                                                   \
+        DR_WALK_VARIANT(V, "%[bvhlh]",                                                                                  \
+                DR_NODE_TEST_S(DR_SEL(SX, DR_A0, DR_A3), DR_SEL(SY, DR_A1, DR_A4), DR_SEL(SZ, DR_A2, DR_A5),            \
+                               DR_SEL(SX, DR_A3, DR_A0), DR_SEL(SY, DR_A4, DR_A1), DR_SEL(SZ, DR_A5, DR_A2)),           \
+                DR_NODE_TEST_S(DR_SEL(SX, DR_B0, DR_B3), DR_SEL(SY, DR_B1, DR_B4), DR_SEL(SZ, DR_B2, DR_B5),            \
+                               DR_SEL(SX, DR_B3, DR_B0), DR_SEL(SY, DR_B4, DR_B1), DR_SEL(SZ, DR_B5, DR_B2)))
+#define DR_WALK_ASM_OCTANTS                                                                                             \
+            asm volatile(                                                                                               \
+                "s_cmp_gt_u32 %[oct], 7\n\t"                                                                            \
+                "s_cbranch_scc1 80f\n\t"                                                                                \
+                "s_bitcmp1_b32 %[oct], 2\n\t"                                                                           \
+                "s_cbranch_scc1 94f\n\t"                                                                                \
+                "s_bitcmp1_b32 %[oct], 1\n\t"                                                                           \
+                "s_cbranch_scc1 92f\n\t"                                                                                \
+                "s_bitcmp1_b32 %[oct], 0\n\t"                                                                           \
+                "s_cbranch_scc1 10f\n\t"                                                                                \
+                "s_branch 00f\n"                                                                                        \
+                "92:\n\t"                                                                                               \
+                "s_bitcmp1_b32 %[oct], 0\n\t"                                                                           \
+                "s_cbranch_scc1 30f\n\t"                                                                                \
+                "s_branch 20f\n"                                                                                        \
+                "94:\n\t"                                                                                               \
+                "s_bitcmp1_b32 %[oct], 1\n\t"                                                                           \
+                "s_cbranch_scc1 96f\n\t"                                                                                \
+                "s_bitcmp1_b32 %[oct], 0\n\t"                                                                           \
+                "s_cbranch_scc1 50f\n\t"                                                                                \
+                "s_branch 40f\n"                                                                                        \
+                "96:\n\t"                                                                                               \
+                "s_bitcmp1_b32 %[oct], 0\n\t"                                                                           \
+                "s_cbranch_scc1 70f\n\t"                                                                                \
+                "s_branch 60f\n"                                                                                        \
+                DR_WALK_OCTANT("0", 0, 0, 0)                                                                            \
+                DR_WALK_OCTANT("1", 1, 0, 0)                                                                            \
+                DR_WALK_OCTANT("2", 0, 1, 0)                                                                            \
+                DR_WALK_OCTANT("3", 1, 1, 0)                                                                            \
+                DR_WALK_OCTANT("4", 0, 0, 1)                                                                            \
+                DR_WALK_OCTANT("5", 1, 0, 1)                                                                            \
+                DR_WALK_OCTANT("6", 0, 1, 1)                                                                            \
+                DR_WALK_OCTANT("7", 1, 1, 1)                                                                            \
+                DR_WALK_VARIANT("8", "%[bvh]", DR_NODE_TEST(DR_A0, DR_A1, DR_A2, DR_A3, DR_A4, DR_A5),                  \
+                                DR_NODE_TEST(DR_B0, DR_B1, DR_B2, DR_B3, DR_B4, DR_B5))                                 \
+                "99:\n\t"                                                                                               \
+                "s_waitcnt lgkmcnt(0)"                                                                                  \
+                : [off] "+s"(off), [leaf] "=s"(leaf), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),   \
+                  [t4] "=&v"(t4), [t5] "=&v"(t5)                                                                        \
+                : [bvh] "s"(bvh), [bvhlh] "s"(bvh_lh), [oct] "s"(octant), [alive] "s"(alive_m), [kx] "v"(kk.x), [ky] "v"(kk.y),    \
+                  [kz] "v"(kk.z), [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z), [tmax] "v"(tmax)                      \
+                : DR_WALK_CLOBBERS, "vcc", "scc")
 #define DR_WALK_ASM(CHECK)                                                                                              \
             asm volatile(                                                                                               \
                 "s_load_dwordx8 " DR_A_ALL ", %[bvh], %[off] offset:0x0\n\t"                                            \
@@ -641,10 +763,13 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
 // ends whenever a hit node is a leaf or the range is left.
 //
 // iv / kk: the per-ray constants of the node test (the ray's 1/d clamped to +-1e18, and -(org*iv)).
+// octant: 0..7 = all live rays point into that octant (bit a set: towards -axis a), the walk from the root then uses the
+// sign-specialised test on bvh_lh; 8 (or RANGE): the general test on bvh.
 template <bool STATS, bool RANGE>
 __device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restrict__ bvh, const TriRec* __restrict__ tri_sorted,
                                                          unsigned off, const unsigned end, f3 org, f3 dn, f3 inv, f3 iv, f3 kk,
-                                                         float tmax, int hi, unsigned long long alive_m, int& n_visit, int& n_leaf) {
+                                                         float tmax, int hi, unsigned long long alive_m, int& n_visit, int& n_leaf,
+                                                         const BvhNode* __restrict__ bvh_lh = nullptr, int octant = 8) {
     for (;;) {
         if (RANGE && off >= end) break;
         int leaf;
@@ -670,7 +795,7 @@ __device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restri
             // without ranges there is no end compare at all: skips that leave the tree land on the sentinel node
             // (all-space box, leaf code BVH_END), which every live lane hits
             if (RANGE) { DR_WALK_ASM("s_cmp_lt_u32 %[off], %[end]\n\ts_cbranch_scc0 8f\n\t"); }
-            else { DR_WALK_ASM(""); }
+            else { DR_WALK_ASM_OCTANTS; }
         }
         if (leaf == BVH_END) break;          // the range is done (or the tree's sentinel was reached)
         if (STATS) n_leaf++;
@@ -1148,7 +1273,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(98))) void k_ff_
                     }
                     if (WALK == 0) {
                         // the whole tree, sentinel-terminated: no end-of-range compares in the walk
-                        alive_m = walk_range<STATS, false>(P.bvh, P.tri_sorted, 0u, end_all, org, dn, inv, iv, kk, tmax, hi, alive_m, n_visit, n_leaf);
+                        // do all live rays point into one octant?  (they run from one patch to one patch: nearly always)
+                        int octant = 8;
+                        if (P.bvh_lh != nullptr) {
+                            const unsigned long long nx = __builtin_amdgcn_ballot_w64(alive && dn.x < 0.0f), ny = __builtin_amdgcn_ballot_w64(alive && dn.y < 0.0f),
+                                                     nz = __builtin_amdgcn_ballot_w64(alive && dn.z < 0.0f);
+                            if ((nx == 0ull || nx == alive_m) && (ny == 0ull || ny == alive_m) && (nz == 0ull || nz == alive_m))
+                                octant = (nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0);
+                        }
+                        octant = __builtin_amdgcn_readfirstlane(octant);
+                        if (STATS && octant == 8 && lane == 0 && P.dbg_lo < 0) atomicAdd(P.pairs_traced + 13, 1ull);
+                        alive_m = walk_range<STATS, false>(P.bvh, P.tri_sorted, 0u, end_all, org, dn, inv, iv, kk, tmax, hi, alive_m, n_visit, n_leaf,
+                                                           P.bvh_lh, octant);
                     }
                     if (PATHS) {
                         alive_m = walk_pair<STATS>(P.bvh, P.tri_sorted, rec_lo, rec_hi, ell, pDl, pDh, leaf_lo, leaf_hi, no_paths, end_all,

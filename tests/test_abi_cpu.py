@@ -129,7 +129,7 @@ def test_tile_kernel_register_budget():
         return int(re.search(name + r": (\d+)", tile[0]).group(1))
     assert 64 <= val("TotalSGPRs") <= 96
     # (a few SGPRs parked in VGPR lanes outside the pair loop are fine; memory spills are not)
-    assert val("SGPRs Spill") <= 8 and val("VGPRs Spill") == 0 and val(r"ScratchSize \[bytes/lane\]") == 0
+    assert val("SGPRs Spill") <= 16 and val("VGPRs Spill") == 0 and val(r"ScratchSize \[bytes/lane\]") == 0
     assert val("VGPRs") <= 64                                   # 8 waves per SIMD by registers
     src = open(os.path.join(ROOT, "daisyriot_amd", "csrc", "geom_kernels.hip")).read()
     named = sorted(set(int(x) for x in re.findall(r'#define DR_[AB][0-7] "s(\d+)"', src.split("#else")[0])))
