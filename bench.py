@@ -45,10 +45,13 @@ def sweep_bytes(nrows, N, S, n_mat):
 
 
 def kernel_source_sha():
-    """identifies the pass kernel a committed PMC file was taken on"""
+    """identifies the pass kernel a committed PMC file was taken on: sweep_kernels.hip and the SweepParams struct"""
+    import re
     h = hashlib.sha256()
-    for f in ("sweep_kernels.hip", "dr_internal.h"):
-        h.update(open(os.path.join(ROOT, "daisyriot_amd", "csrc", f), "rb").read())
+    csrc = os.path.join(ROOT, "daisyriot_amd", "csrc")
+    h.update(open(os.path.join(csrc, "sweep_kernels.hip"), "rb").read())
+    m = re.search(r"struct SweepParams \{.*?\n\};", open(os.path.join(csrc, "dr_internal.h")).read(), flags=re.S)
+    h.update((m.group(0) if m else "").encode())
     return h.hexdigest()[:16]
 
 

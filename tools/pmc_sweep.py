@@ -9,9 +9,12 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def sha():
+    # the same function as bench.py's kernel_source_sha
     h = hashlib.sha256()
-    for f in ("sweep_kernels.hip", "dr_internal.h"):
-        h.update(open(os.path.join(root, "daisyriot_amd", "csrc", f), "rb").read())
+    csrc = os.path.join(root, "daisyriot_amd", "csrc")
+    h.update(open(os.path.join(csrc, "sweep_kernels.hip"), "rb").read())
+    m = re.search(r"struct SweepParams \{.*?\n\};", open(os.path.join(csrc, "dr_internal.h")).read(), flags=re.S)
+    h.update((m.group(0) if m else "").encode())
     return h.hexdigest()[:16]
 
 
