@@ -103,6 +103,10 @@ struct dr_context {
     unsigned long long blocks_nonzero = 0, blocks_total = 0;
     float* d_stage = nullptr;     // N x S staging for layout conversion on read-back
     float* d_rgb = nullptr;       // display colours of the local rows (nrows x 3), valid after dr_display_patch_colors
+    // buffers of dr_display_vertex_colors, kept between calls (a viewer asks after every pass)
+    int *d_voff = nullptr, *d_vadj = nullptr;
+    float *d_vout = nullptr, *d_vin = nullptr;
+    size_t voff_n = 0, vadj_n = 0, vout_n = 0, vin_n = 0;
     bool have_rgb = false;
     int ksplit = 1;
     int cur = 0;
@@ -133,6 +137,8 @@ void free_solver(dr_context* c) {
     hipFree(c->d_tickets); hipFree(c->d_blk_sums); hipFree(c->d_ctl);
     c->d_tickets = nullptr; c->d_blk_sums = nullptr; c->d_ctl = nullptr;
     hipFree(c->d_rgb); c->d_rgb = nullptr; c->have_rgb = false;
+    hipFree(c->d_voff); hipFree(c->d_vadj); hipFree(c->d_vout); hipFree(c->d_vin);
+    c->d_voff = c->d_vadj = nullptr; c->d_vout = c->d_vin = nullptr; c->voff_n = c->vadj_n = c->vout_n = c->vin_n = 0;
     c->d_M = c->d_E = c->d_B = c->d_R[0] = c->d_R[1] = nullptr; c->d_mat = nullptr;
     c->have_solver = false;
 }
@@ -878,20 +884,26 @@ int dr_display_vertex_colors(dr_context* c, const float* rgb_all, const int32_t*
     const int n_adj = vtx_off[V];
     for (int k = 0; k < n_adj; k++)
         if (vtx_tri[k] < 0 || vtx_tri[k] >= c->N) return fail(DR_ERR_INVALID, "vtx_tri[%d] = %d out of range", k, vtx_tri[k]);
-    int *d_off = nullptr, *d_adj = nullptr;
-    float *d_out = nullptr, *d_in = nullptr;
-    auto cleanup = [&]() { hipFree(d_off); hipFree(d_adj); hipFree(d_out); hipFree(d_in); };
-    hipError_t e = hipMalloc(&d_off, sizeof(int) * ((size_t)V + 1));
-    if (e == hipSuccess) e = hipMalloc(&d_adj, sizeof(int) * (size_t)std::max(n_adj, 1));
-    if (e == hipSuccess) e = hipMalloc(&d_out, sizeof(float) * 3 * (size_t)V);
-    if (e == hipSuccess && rgb_all) e = hipMalloc(&d_in, sizeof(float) * 3 * (size_t)c->N);
+    // device buffers are kept in the context and only grow
+    auto grow = [](auto*& ptr, size_t& have, size_t want, size_t elem) -> hipError_t {
+        if (have >= want && ptr) return hipSuccess;
+        hipFree(ptr); ptr = nullptr; have = 0;
+        hipError_t er = hipMalloc(&ptr, want * elem);
+        if (er == hipSuccess) have = want;
+        return er;
+    };
+    hipError_t e = grow(c->d_voff, c->voff_n, (size_t)V + 1, sizeof(int));
+    if (e == hipSuccess) e = grow(c->d_vadj, c->vadj_n, (size_t)std::max(n_adj, 1), sizeof(int));
+    if (e == hipSuccess) e = grow(c->d_vout, c->vout_n, (size_t)3 * V, sizeof(float));
+    if (e == hipSuccess && rgb_all) e = grow(c->d_vin, c->vin_n, (size_t)3 * c->N, sizeof(float));
+    int *d_off = c->d_voff, *d_adj = c->d_vadj;
+    float *d_out = c->d_vout, *d_in = c->d_vin;
     if (e == hipSuccess) e = hipMemcpyAsync(d_off, vtx_off, sizeof(int) * ((size_t)V + 1), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && n_adj > 0) e = hipMemcpyAsync(d_adj, vtx_tri, sizeof(int) * (size_t)n_adj, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && rgb_all) e = hipMemcpyAsync(d_in, rgb_all, sizeof(float) * 3 * (size_t)c->N, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = launch_vertex_colors(c->stream, rgb_all ? d_in : c->d_rgb, V, d_off, d_adj, d_out);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(float) * 3 * (size_t)V, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    cleanup();
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? DR_ERR_NOMEM : DR_ERR_DEVICE, "vertex colours: %s", hipGetErrorString(e));
     return DR_OK;
 }

@@ -562,8 +562,19 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
         const f3 ta = f3{ A[0], A[1], A[2] };
         const f3 te1 = f3{ A[3], B[0], B[1] };
         const f3 te2 = f3{ B[2], B[3], C3[0] };
-        float tt;
-        const bool h = tri_hit(org, dn, ta, te1, te2, tt);
+        // tri_hit in two halves: a hit needs 0 <= u and (v >= 0, u + v <= 1, hence) u <= 1 -- when no gated lane has such a u
+        // the second half (a cross product, two dot products) is not evaluated.  Same operations, same order, same result.
+        const f3 pv = cross3(dn, te2);
+        const float det = dot3(te1, pv);
+        const float idet = 1.0f / det;
+        const f3 tv = org - ta;
+        const float u = dot3(tv, pv) * idet;
+        const unsigned long long um = gm & __builtin_amdgcn_ballot_w64((u >= 0.0f) & (u <= 1.0f));
+        if (um == 0ull) continue;
+        const f3 qv = cross3(tv, te1);
+        const float v = dot3(dn, qv) * idet;
+        const float tt = dot3(te2, qv) * idet;
+        const bool h = (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (tt > 0.0f);
         // closest hit is not `hi`: something nearer, or an equal-t hit of lower id
         const unsigned long long bm = gm & __builtin_amdgcn_ballot_w64(h & ((tt < tmax) | ((tt == tmax) & (tk < hi))));
         blocked_m |= bm;
