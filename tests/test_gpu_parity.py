@@ -282,7 +282,7 @@ def test_bvh_invariants():
 
 
 def test_column_split_sweep_matches_oracle(tmp_path):
-    """small row shards cut the columns into ranges (k_sweep<..., SPLIT> + k_sweep_epilogue);
+    """small row shards cut the columns into ranges (k_sweep<..., SPLIT>: the last range of a row block adds the partial sums);
     forced here through DR_SWEEP_KSPLIT in a child process (the knob is read once per process)"""
     import subprocess
     import sys
@@ -616,6 +616,8 @@ def test_multi_rank_assembly_with_ray_count_exchange(world, n, rule, uv50):
             assert np.array_equal(_bits(c.read_rows(row0, nrows)), _bits(F[row0:row0 + nrows]))
         with pytest.raises(api.DaisyRiotError):
             c.assemble_finish()                                    # nothing pending
+        with pytest.raises(api.DaisyRiotError):
+            c.vis_exchange_export(0)                               # no split assembly in flight
 
 
 @pytest.mark.parametrize("S,n,world,rank", [(8, 8192, 1, 0), (3, 6000, 1, 0), (9, 8192, 1, 0), (16, 6000, 1, 0),
@@ -757,3 +759,28 @@ def test_shaft_list_option_is_exact(uv50, monkeypatch):
             vis, F = c.read_visibility(0, sc.N), c.read_rows(0, sc.N)
         Fo, viso, _ = ob.assemble_rows(ob.Mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n), uv50, bvh=True)
         assert np.array_equal(vis, viso) and np.array_equal(_bits(F), _bits(Fo))
+
+
+@pytest.mark.parametrize("S", [3, 9])
+def test_converge_on_a_column_split_pass(S):
+    """8192 patches on one rank: few enough row blocks that the pass cuts its columns into (tapered) ranges by itself -- the
+    in-launch hand-offs (partial sums -> last range of a row block; row blocks' residual sums -> last row block) feed the
+    device-side convergence test: same pass count as the oracle, sums in the tails equal to the residual's sums"""
+    n = 8192
+    sc = scenes.cornell_box(n, S=S, fluorescent=(S >= 8))
+    E = sc.emission(7.0)
+    with _ctx(sc) as c:
+        c.integrand_only()                                   # unoccluded F: rows sum to about 1, the materials absorb
+        F = c.read_rows(0, sc.N)
+        c.solver_init(E, sc.M, sc.mat_of_patch)
+        thr, per_bin = (1e-2, True) if S == 3 else (20.0, False)
+        it = c.converge(thr, per_bin=per_bin, max_iters=200)
+        Bg, Rg = c.read()
+        sums = c.residual_sums()
+        it_o, Ro, Bo = ob.converge(F, sc.M, sc.mat_of_patch, E, thr, per_bin, 200)
+        assert it == it_o and 2 < it < 200
+        assert (np.abs(Bg - Bo) / (np.abs(Bo).max(axis=0) + 1e-30)).max() < 1e-4
+        assert np.allclose(sums, Rg.astype(np.float64).sum(axis=0), rtol=1e-9)
+        c.step(2)                                            # plain passes afterwards: sums on demand
+        _, R2 = c.read(B=False)
+        assert np.allclose(c.residual_sums(), R2.astype(np.float64).sum(axis=0), rtol=1e-9)
