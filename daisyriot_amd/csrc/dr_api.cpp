@@ -407,8 +407,11 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     c->n_nodes = 2 * N - 1;
     HIPCHK(hipMalloc(&c->d_bvh, sizeof(BvhNode) * ((size_t)c->n_nodes + 2)));     // + the sentinel + one node the walk's prefetch may touch
     HIPCHK(hipMalloc(&c->d_bvh_lh, sizeof(BvhNode) * ((size_t)c->n_nodes + 2)));
-    HIPCHK(hipMalloc(&c->d_path_rec, sizeof(BvhNode) * (size_t)N * PATH_RECS));
-    HIPCHK(hipMalloc(&c->d_path_hdr, sizeof(PathHdr) * (size_t)N));
+    // the per-patch path records (1 KiB per patch) are only built for the experimental walk that uses them (DR_PATHS=1)
+    if (const char* e = getenv("DR_PATHS"); e && atoi(e) != 0) {
+        HIPCHK(hipMalloc(&c->d_path_rec, sizeof(BvhNode) * (size_t)N * PATH_RECS));
+        HIPCHK(hipMalloc(&c->d_path_hdr, sizeof(PathHdr) * (size_t)N));
+    }
     HIPCHK(hipMemcpyAsync(c->d_vtx, vertices, sizeof(float) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_nrm, normals, sizeof(float) * 3 * (size_t)Nn, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_tv, tv, sizeof(int) * 3 * (size_t)N, hipMemcpyHostToDevice, c->stream));
@@ -491,7 +494,8 @@ static int assemble_launch(dr_context* c, int K, float eps, int rule, int trace,
         { const char* e = getenv("DR_OCTANT"); p.bvh_lh = (e && !atoi(e)) ? nullptr : c->d_bvh_lh; }
         // DR_PATHS=1: the pairs' walks run over the two patches' path records instead of starting at the root (exact, measured
         // slower: profiles/r02/assembly_notes.md)
-        { const char* e = getenv("DR_PATHS"); const bool on = e ? atoi(e) != 0 : false; p.path_rec = on ? c->d_path_rec : nullptr; p.path_hdr = on ? c->d_path_hdr : nullptr; }
+        { const char* e = getenv("DR_PATHS"); const bool on = (e ? atoi(e) != 0 : false) && c->d_path_rec && c->d_path_hdr;
+          p.path_rec = on ? c->d_path_rec : nullptr; p.path_hdr = on ? c->d_path_hdr : nullptr; }
         p.vx_mode = vx_mode; p.vx_rank = c->rank; p.vx_tiles_per_rank = c->rpr / TILE; p.vsend = c->d_vsend; p.vrecv = c->d_vrecv;
         // tile-pair shaft culling (geom_kernels.hip), off unless DR_SHAFT=1: exact, but measured slower than walks from
         // the root (profiles/r02/assembly_notes.md); DR_SHAFT_MIN = nodes below which a subtree is listed whole

@@ -732,11 +732,19 @@ def test_group_one_process_several_ranks(world, S, n, uv50):
         assert np.allclose(Bc, Bc1, rtol=2e-6, atol=1e-12)
 
 
-def test_shaft_list_option_is_exact(uv50, monkeypatch):
-    """DR_SHAFT=1 (tile-pair shaft culling, off by default): same ray counts and F as the brute-force oracle on a soup far from
-    the origin, on the Cornell box, and with an origin offset that throws rays out of their tile's box (walks from the root)"""
-    monkeypatch.setenv("DR_SHAFT", "1")
-    for mn in ("8", "128"):
+@pytest.mark.parametrize("mode", ["shaft", "paths", "general-node-test"])
+def test_alternative_walks_are_exact(mode, uv50, monkeypatch):
+    """The walks that are built, exact and not shipped as the default (profiles/r02/assembly_notes.md) -- DR_SHAFT=1: tile-pair
+    shaft lists; DR_PATHS=1: per-patch path records; DR_OCTANT=0: the general node test for every pair -- give the same ray
+    counts and F as the brute-force oracle: on a soup far from the origin, on the Cornell box, and with an origin offset that
+    throws rays out of their tile's box (shaft lists: those pairs walk from the root)"""
+    if mode == "shaft":
+        monkeypatch.setenv("DR_SHAFT", "1")
+    elif mode == "paths":
+        monkeypatch.setenv("DR_PATHS", "1")
+    else:
+        monkeypatch.setenv("DR_OCTANT", "0")
+    for mn in (("8", "128") if mode == "shaft" else ("128",)):
         monkeypatch.setenv("DR_SHAFT_MIN", mn)
         rs = np.random.RandomState(5)
         n = 300
@@ -759,6 +767,17 @@ def test_shaft_list_option_is_exact(uv50, monkeypatch):
             vis, F = c.read_visibility(0, sc.N), c.read_rows(0, sc.N)
         Fo, viso, _ = ob.assemble_rows(ob.Mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n), uv50, bvh=True)
         assert np.array_equal(vis, viso) and np.array_equal(_bits(F), _bits(Fo))
+    # a single triangle and a two-triangle scene: the paths have depth 0 / 1
+    if mode == "paths":
+        sc = scenes.cornell_box(1500, S=3)
+        for n in (1, 2, 3):
+            tvs, tns = sc.tri_v[:n], sc.tri_n[:n]
+            with api.Context(0) as c:
+                c.set_mesh(sc.vertices, sc.normals, tvs, tns)
+                c.assemble(uv50, keep_visibility=True)
+                vis, F = c.read_visibility(0, n), c.read_rows(0, n)
+            Fo, viso, _ = ob.assemble_rows(ob.Mesh(sc.vertices, sc.normals, tvs, tns), uv50, bvh=False)
+            assert np.array_equal(vis, viso) and np.array_equal(_bits(F), _bits(Fo))
 
 
 @pytest.mark.parametrize("S", [3, 9])
