@@ -177,15 +177,23 @@ def launch_ranks(args, argv):
     import torch
 
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    fake = None
+    if args.shared_gpu_rehearsal:
+        fake_dir = os.path.join(ROOT, "tests", "fake_rccl")
+        subprocess.check_call(["make", "-C", fake_dir], stdout=subprocess.DEVNULL)
+        fake = os.path.join(fake_dir, "libfake_rccl.so")
+    elif have < args.gpus:
         sys.exit("bench.py --gpus %d: this box has %d GPU(s); the multi-process path needs one GPU per rank "
                  "(rehearse the single-process path on one GPU with: --group --gpus %d --devices %s)"
                  % (args.gpus, have, args.gpus, ",".join(["0"] * args.gpus)))
     port = free_port()
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if fake else r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if fake:
+            env["DR_RCCL_LIB"] = fake
+            env.setdefault("FAKE_RCCL_SLOT_MB", "64")          # mailbox size of the stand-in: >= one all-to-all block
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else sys.stderr))
     rc = 0
@@ -220,6 +228,10 @@ def main():
     ap.add_argument("--rehearse-comm", action="store_true",
                     help="single rank only: still create the torch process group and the library's RCCL communicator "
                          "(all-gather of one chunk per pass), to rehearse the multi-GPU code path on a one-GPU box")
+    ap.add_argument("--shared-gpu-rehearsal", action="store_true",
+                    help="NOT a measurement: run the --gpus N ranks as N processes on GPU 0, torch.distributed over gloo and the "
+                         "library's collectives over tests/fake_rccl (real RCCL refuses several ranks on one device) -- a rehearsal "
+                         "of the multi-process code path on a one-GPU box")
     ap.add_argument("--group", action="store_true",
                     help="one process drives all --gpus devices through the library's dr_group (no torch.distributed)")
     ap.add_argument("--devices", type=str, default=None,
@@ -253,10 +265,15 @@ def main():
         sys.exit("bench.py needs a GPU (no CPU fallback for the hot path)")
     torch.cuda.set_device(local_rank)
     use_comm = world > 1 or args.rehearse_comm
+    rehearsal = args.shared_gpu_rehearsal and world > 1
+    tdev = "cpu" if rehearsal else "cuda"          # where torch.distributed's own tensors live (gloo in the rehearsal)
     if use_comm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if use_comm:
@@ -264,7 +281,7 @@ def main():
 
     def gather_f64(vals):
         """every rank's values -> [world][len(vals)] on every rank"""
-        t = torch.tensor(vals, dtype=torch.float64, device="cuda")
+        t = torch.tensor(vals, dtype=torch.float64, device=tdev)
         if not use_comm:
             return [list(map(float, t))]
         out = [torch.zeros_like(t) for _ in range(world)]
@@ -279,7 +296,7 @@ def main():
     ctx = api.Context(local_rank)
     ctx.set_shard(rank, world)
     if use_comm:
-        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        idt = torch.zeros(128, dtype=torch.uint8, device=tdev)
         if rank == 0:
             idt.copy_(torch.from_numpy(api.comm_unique_id()))
         dist.broadcast(idt, 0)
@@ -392,7 +409,9 @@ def main():
                                    % (N, S, args.rays, world),
                        "patches": N, "bins": S, "rays_per_pair": args.rays,
                        "F_bytes_per_gpu": int(info.bytes_F), "rows_per_gpu": [q["rows"] for q in per_rank],
-                       "launch": "one process per GPU (torch.distributed / RCCL)"},
+                       "launch": "one process per GPU (torch.distributed / RCCL)" if not rehearsal else
+                                 "REHEARSAL, not a measurement: %d processes share GPU 0, gloo + tests/fake_rccl" % world},
+            "rehearsal_on_shared_gpu": bool(rehearsal),
             # what every rank's RCCL communicator itself reports (ncclCommCount / ncclCommUserRank): 0 = no communicator
             "rccl_world": int(per[0][3]), "rccl_ranks": [int(p[4]) for p in per],
             "exchange_us_per_pass": (dt / args.steps * 1e3 - max(p[1] for p in per)) * 1e3,

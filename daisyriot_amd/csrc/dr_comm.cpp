@@ -5,6 +5,7 @@
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -38,9 +39,14 @@ Api& api() {
     static Api a;
     static std::once_flag once;
     std::call_once(once, [] {
+        // DR_RCCL_LIB: bind this library instead (tests: a loop-back stand-in that lets several ranks share one GPU)
+        if (const char* forced = getenv("DR_RCCL_LIB")) {
+            a.h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+            if (!a.h) { a.err = std::string("DR_RCCL_LIB: ") + dlerror(); return; }
+        }
         // prefer a copy already mapped into the process (same SONAME as torch's bundled one)
         const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-        for (const char* n : names) {
+        if (!a.h) for (const char* n : names) {
             a.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
             if (a.h) break;
         }
