@@ -1092,11 +1092,12 @@ __device__ __forceinline__ int build_shaft_list(const BvhNode* __restrict__ bvh,
 // STATS builds count BVH visits with global atomics inside the pair loop; that store makes
 // the compiler give up scalar (SMEM) loads for nodes and triangles, so it is a separate,
 // debug-only instantiation.
-// amdgpu_num_sgpr: at most 90 allocatable + 6 (VCC, FLAT_SCRATCH, XNACK) = 96, the most a CU still admits 7 blocks with
+// amdgpu_num_sgpr(82) -> 80 SGPRs in the code object: the most with which a CU admits 8 blocks of 256 threads (the rest is
+// parked in VGPR lanes outside the pair loop); with 64 VGPRs and 19.7 KB of LDS that is 8 waves per SIMD, the hardware's maximum
 // WALK: 0 = every pair's walk starts at the root (shipped); 1 = over the tile pair's shaft list (build_shaft_list); 2 = over the
 // two patches' path records (walk_pair).  1 and 2 are exact and measured slower: profiles/r02/assembly_notes.md.
 template <int NT, bool STATS, int WALK>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(98))) void k_ff_tiles(TileParams P) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82))) void k_ff_tiles(TileParams P) {
     constexpr bool SHAFT = (WALK == 1), PATHS = (WALK == 2);
     const int t = blockIdx.x;
     const int o = P.tile0 + blockIdx.y;
@@ -1121,8 +1122,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(98))) void k_ff_
 
     __shared__ float sRec[2][TILE][REC_STRIDE];
     __shared__ unsigned char sVis[TILE][VIS_STRIDE];   // ray count per pair, 255 = not traced
-    __shared__ unsigned short sQueue[TILE * TILE];
+    // The queue of traced pairs (up to 4096 entries of 2 bytes): its second half lives in sRec's memory -- the patch records are
+    // not read while the pairs are traced (the walk takes the triangles from global memory) and are loaded again for the
+    // write-out.  With that the block needs 19.7 instead of 23.3 KB of LDS, and with the kernel's 80 SGPRs a CU holds 8 blocks
+    // instead of 7.  sAct: one bit per pair, "traced", between the pass that evaluates the integrand (reads sRec) and the
+    // pass that fills the queue (overwrites it).
+    __shared__ unsigned short sQueue[TILE * TILE / 2];
+    __shared__ unsigned sAct[TILE * TILE / 32];
     __shared__ int sCount;
+    unsigned short* const sQueueB = reinterpret_cast<unsigned short*>(&sRec[0][0][0]);
+    static_assert(sizeof(float) * 2 * TILE * REC_STRIDE >= sizeof(unsigned short) * TILE * TILE / 2, "second half of the queue does not fit the records");
     __shared__ float sBox[2][6];                        // union of the gate boxes of the I / J tile's patches: lo[3], hi[3]
     __shared__ uint2 sList[LIST_MAX];                   // the tile pair's candidate node ranges (build_shaft_list)
     __shared__ int sNList;
@@ -1178,10 +1187,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(98))) void k_ff_
             sVis[i][j] = 255;
         }
         const unsigned long long m = __ballot(act);
+        if (lane == 0 && p < TILE * TILE) { sAct[p >> 5] = (unsigned)m; sAct[(p >> 5) + 1] = (unsigned)(m >> 32); }    // p is a multiple of 64 here
+    }
+    __syncthreads();
+    // the queue, in the order of p (sRec is dead from here to the write-out)
+    for (int p0 = 0; p0 < (from_slot ? 0 : TILE * TILE); p0 += NT) {
+        const int p = p0 + tid;
+        const bool act = (p < TILE * TILE) && ((sAct[p >> 5] >> (p & 31)) & 1u);
+        const unsigned long long m = __ballot(act);
         int base = 0;
         if (lane == 0 && m) base = atomicAdd(&sCount, __popcll(m));
         base = __shfl(base, 0);
-        if (act) sQueue[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
+        if (act) {
+            const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (at < TILE * TILE / 2) sQueue[at] = (unsigned short)p;
+            else sQueueB[at - TILE * TILE / 2] = (unsigned short)p;
+        }
     }
     __syncthreads();
     const int n_act = sCount;
@@ -1215,7 +1236,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(98))) void k_ff_
         const int n_act_u = __builtin_amdgcn_readfirstlane(n_act);
         const int n_list = use_shaft ? __builtin_amdgcn_readfirstlane(sNList) : 1;
         for (int q = wave; q < n_act_u; q += NT / 64) {
-            const int p = __builtin_amdgcn_readfirstlane((int)sQueue[q]);
+            const int p = __builtin_amdgcn_readfirstlane((int)(q < TILE * TILE / 2 ? sQueue[q] : sQueueB[q - TILE * TILE / 2]));
             const int i = p >> 6, j = p & 63;
             const int lo = I0 + i, hi = J0 + j;
             const TriRec Tl = P.tri[lo];
@@ -1322,6 +1343,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(98))) void k_ff_
         }
     }
     __syncthreads();
+    if (!from_slot) {
+        // the patch records again (the queue's second half lay over them)
+        for (int x = tid; x < 2 * TILE * 20; x += NT) {
+            int side = x / (TILE * 20);
+            int r = (x - side * TILE * 20) / 20, c = x % 20;
+            int g = (side ? J0 : I0) + r;
+            sRec[side][r][c] = (g < P.N) ? reinterpret_cast<const float*>(P.patch + g)[c] : 0.0f;
+        }
+        __syncthreads();
+    }
     if (tid == 0 && n_act > 0 && P.trace && P.pairs_traced) atomicAdd(P.pairs_traced, (unsigned long long)n_act);
     if (P.vx_mode == 1 && !t_owned) {
         // this pair is also the other rank's: hand its ray counts over (slot of own tile o, foreign tile t)

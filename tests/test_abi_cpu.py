@@ -115,9 +115,10 @@ def test_ray_count_exchange_assignment_is_a_balanced_partition():
 
 
 def test_tile_kernel_register_budget():
-    """k_ff_tiles' hand-written BVH walk names its node registers (s[48:63]) instead of letting the compiler allocate them.
-    Static check on the built code object's resource usage: the named registers lie inside the kernel's SGPR allocation, nothing
-    spills, and the count stays at or below 96 -- above that a CU admits 6 instead of 7 blocks (MI355X_MICROARCH.md, Residency)"""
+    """k_ff_tiles' hand-written BVH walk names its node registers (s[48:63]) instead of letting the compiler allocate them, and the
+    kernel's speed hangs on 8 resident blocks per CU (7 -> 8: -13 % time).  Static check on the built code object's resource
+    report: at most 80 SGPRs (81 - 96 would admit 7 blocks: MI355X_MICROARCH.md, Residency), at most 64 VGPRs, at most 20 KiB
+    of LDS per block, nothing spilled to memory; the named registers lie inside the allocation and in the clobber list"""
     path = os.path.join(ROOT, "daisyriot_amd", "lib", "geom_kernels.resources.txt")
     if not os.path.exists(path):
         pytest.skip("library built without the resource report")
@@ -127,10 +128,12 @@ def test_tile_kernel_register_budget():
     assert len(tile) == 1, "default tile kernel not found in the resource report"
     def val(name):
         return int(re.search(name + r": (\d+)", tile[0]).group(1))
-    assert 64 <= val("TotalSGPRs") <= 96
-    # (a few SGPRs parked in VGPR lanes outside the pair loop are fine; memory spills are not)
-    assert val("SGPRs Spill") <= 16 and val("VGPRs Spill") == 0 and val(r"ScratchSize \[bytes/lane\]") == 0
+    assert 64 <= val("TotalSGPRs") <= 80
+    # (SGPRs parked in VGPR lanes outside the pair loop are fine; memory spills are not)
+    assert val("VGPRs Spill") == 0 and val(r"ScratchSize \[bytes/lane\]") == 0
     assert val("VGPRs") <= 64                                   # 8 waves per SIMD by registers
+    assert val(r"LDS Size \[bytes/block\]") <= 20480            # 8 blocks per CU by LDS
+    assert val(r"Occupancy \[waves/SIMD\]") == 8
     src = open(os.path.join(ROOT, "daisyriot_amd", "csrc", "geom_kernels.hip")).read()
     named = sorted(set(int(x) for x in re.findall(r'#define DR_[AB][0-7] "s(\d+)"', src.split("#else")[0])))
     assert named == list(range(48, 64))
