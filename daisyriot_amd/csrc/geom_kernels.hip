@@ -119,19 +119,40 @@ __device__ __forceinline__ void tri_bounds(const TriRec& T, float lo[3], float h
     for (int a = 0; a < 3; a++) { lo[a] = T.lo[a]; hi[a] = T.hi[a]; }
 }
 
-__global__ void k_morton(int N, const TriRec* __restrict__ tri, float3 slo, float3 sinv,
+// key_mode 0: 63-bit Morton code of the gate box's centre (x, y, z interleaved).
+// key_mode 1 / 2: three leading bits = the orientation class of the triangle (dominant axis of its geometric normal and the
+// normal's sign), then 60 bits of Morton code -- in x, y, z order (1) or with the dominant axis leading (2).  The top of the
+// tree then separates surfaces by the way they face before it separates space: parallel sheets make thin nodes, where
+// Morton octants of a room's corner make fat ones that every ray through the room's interior enters.  Any key gives a valid
+// tree (and bit-identical results: the per-triangle tests define the hits); the key only decides how many nodes a walk visits.
+__global__ void k_morton(int N, const TriRec* __restrict__ tri, float3 slo, float3 sinv, int key_mode,
                          unsigned long long* __restrict__ keys, int* __restrict__ vals) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= N) return;
     float lo[3], hi[3];
-    tri_bounds(tri[t], lo, hi);
-    float cx = (0.5f * (lo[0] + hi[0]) - slo.x) * sinv.x;
-    float cy = (0.5f * (lo[1] + hi[1]) - slo.y) * sinv.y;
-    float cz = (0.5f * (lo[2] + hi[2]) - slo.z) * sinv.z;
-    unsigned int ix = (unsigned int)fminf(fmaxf(cx * 2097152.0f, 0.0f), 2097151.0f);
-    unsigned int iy = (unsigned int)fminf(fmaxf(cy * 2097152.0f, 0.0f), 2097151.0f);
-    unsigned int iz = (unsigned int)fminf(fmaxf(cz * 2097152.0f, 0.0f), 2097151.0f);
-    keys[t] = (expand21(ix) << 2) | (expand21(iy) << 1) | expand21(iz);
+    const TriRec T = tri[t];
+    tri_bounds(T, lo, hi);
+    float c[3];
+    c[0] = (0.5f * (lo[0] + hi[0]) - slo.x) * sinv.x;
+    c[1] = (0.5f * (lo[1] + hi[1]) - slo.y) * sinv.y;
+    c[2] = (0.5f * (lo[2] + hi[2]) - slo.z) * sinv.z;
+    if (key_mode == 0) {
+        unsigned int ix = (unsigned int)fminf(fmaxf(c[0] * 2097152.0f, 0.0f), 2097151.0f);
+        unsigned int iy = (unsigned int)fminf(fmaxf(c[1] * 2097152.0f, 0.0f), 2097151.0f);
+        unsigned int iz = (unsigned int)fminf(fmaxf(c[2] * 2097152.0f, 0.0f), 2097151.0f);
+        keys[t] = (expand21(ix) << 2) | (expand21(iy) << 1) | expand21(iz);
+    } else {
+        float n[3] = { T.e1[1] * T.e2[2] - T.e1[2] * T.e2[1], T.e1[2] * T.e2[0] - T.e1[0] * T.e2[2],
+                       T.e1[0] * T.e2[1] - T.e1[1] * T.e2[0] };
+        int dom = 0;
+        if (fabsf(n[1]) > fabsf(n[dom])) dom = 1;
+        if (fabsf(n[2]) > fabsf(n[dom])) dom = 2;
+        const unsigned long long cls = (unsigned long long)(dom * 2 + (n[dom] < 0.0f ? 1 : 0));
+        unsigned int q[3];
+        for (int a = 0; a < 3; a++) q[a] = (unsigned int)fminf(fmaxf(c[a] * 1048576.0f, 0.0f), 1048575.0f);
+        const int a0 = key_mode == 2 ? dom : 0, a1 = (a0 + 1) % 3, a2 = (a0 + 2) % 3;
+        keys[t] = (cls << 60) | (expand21(q[a0]) << 2) | (expand21(q[a1]) << 1) | expand21(q[a2]);
+    }
     vals[t] = t;
 }
 
@@ -336,7 +357,9 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
         int* pre = esize + nn;
         int* pos = pre + nn;
         const int nb = (N + 255) / 256;
-        hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, st, N, tri, lo3, inv3, keys, vals);
+        const char* km = getenv("DR_BVH_KEY");
+        const int key_mode = km ? atoi(km) : 0;
+        hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, st, N, tri, lo3, inv3, key_mode, keys, vals);
         DR_TRY(hipGetLastError());
         DR_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (unsigned int)N, 0, 64, st));
         DR_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
@@ -617,6 +640,36 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
                 "v_min_f32_e32 %[t0], %[t0], %[tmax]\n\t"                     \
                 "v_cmp_le_f32_e32 vcc, %[t3], %[t0]\n\t"                      \
                 "s_and_b64 vcc, vcc, %[alive]\n\t"
+// The two tests as the walk from the root uses them (suffix X): EXEC holds the live rays while the walk runs, so the compare's
+// VCC needs no s_and with the liveness mask and the branch reads VCCZ; and the ray parameter is scaled by a power of two
+// (TileParams::t_scale, exact) that puts tmax below 1/2, so that the `clamp` bit on ONE near-plane fma gives max(., 0) for
+// free: max3(clamp(tn_x), tn_y, tn_z) = max(tn_x, tn_y, tn_z, 0) unless tn_x > 1 > tmax, where both forms reject.
+// 10 vector instructions (13 for the general form), no scalar one.
+#define DR_NODE_TEST_X(CX, CY, CZ, HX, HY, HZ)                                \
+                "v_fma_f32 %[t0], " CX ", %[ix], %[kx]\n\t"                   \
+                "v_fma_f32 %[t1], " CY ", %[iy], %[ky]\n\t"                   \
+                "v_fma_f32 %[t2], " CZ ", %[iz], %[kz]\n\t"                   \
+                "v_fma_f32 %[t3], " HX ", -|%[ix]|, %[t0] clamp\n\t"          \
+                "v_fma_f32 %[t0], " HX ", |%[ix]|, %[t0]\n\t"                 \
+                "v_fma_f32 %[t4], " HY ", -|%[iy]|, %[t1]\n\t"                \
+                "v_fma_f32 %[t1], " HY ", |%[iy]|, %[t1]\n\t"                 \
+                "v_fma_f32 %[t5], " HZ ", -|%[iz]|, %[t2]\n\t"                \
+                "v_fma_f32 %[t2], " HZ ", |%[iz]|, %[t2]\n\t"                 \
+                "v_max3_f32 %[t3], %[t3], %[t4], %[t5]\n\t"                   \
+                "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t"                   \
+                "v_min_f32_e32 %[t0], %[t0], %[tmax]\n\t"                     \
+                "v_cmp_le_f32_e32 vcc, %[t3], %[t0]\n\t"
+#define DR_NODE_TEST_SX(NX, NY, NZ, FX, FY, FZ)                               \
+                "v_fma_f32 %[t3], " NX ", %[ix], %[kx] clamp\n\t"             \
+                "v_fma_f32 %[t4], " NY ", %[iy], %[ky]\n\t"                   \
+                "v_fma_f32 %[t5], " NZ ", %[iz], %[kz]\n\t"                   \
+                "v_fma_f32 %[t0], " FX ", %[ix], %[kx]\n\t"                   \
+                "v_fma_f32 %[t1], " FY ", %[iy], %[ky]\n\t"                   \
+                "v_fma_f32 %[t2], " FZ ", %[iz], %[kz]\n\t"                   \
+                "v_max3_f32 %[t3], %[t3], %[t4], %[t5]\n\t"                   \
+                "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t"                   \
+                "v_min_f32_e32 %[t0], %[t0], %[tmax]\n\t"                     \
+                "v_cmp_le_f32_e32 vcc, %[t3], %[t0]\n\t"
 // The sentinel-terminated walk from the root in nine variants inside ONE asm statement (one set of operands, no control
 // flow for the compiler to reason about): V = 0..7 the sign-specialised test on bvh_lh for that octant (bit a of V set:
 // the rays point towards -axis a, the near corner's coordinate a is the upper one), "8" the general test on bvh.  Local
@@ -624,6 +677,8 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
 #define DR_SEL(S, LO, HI) DR_SEL_##S(LO, HI)
 #define DR_SEL_0(LO, HI) LO
 #define DR_SEL_1(LO, HI) HI
+// Offsets: set A holds the node at %[off], set B the one at %[off] + 32; the offset register moves by 64 after two nodes
+// entered in a row (and on every skip), the loads carry the rest as immediates.
 #define DR_WALK_VARIANT(V, BVH, TESTA, TESTB)                                                                           \
                 V "0:\n\t"                                                                                              \
                 "s_load_dwordx8 " DR_A_ALL ", " BVH ", %[off] offset:0x0\n\t"                                           \
@@ -631,16 +686,15 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
                 V "1:\n\t"                                                                                              \
                 "s_load_dwordx8 " DR_B_ALL ", " BVH ", %[off] offset:0x20\n\t"                                          \
                 TESTA                                                                                                   \
-                "s_cbranch_scc0 " V "3f\n\t"                                                                            \
-                "s_add_u32 %[off], %[off], 32\n\t"                                                                      \
+                "s_cbranch_vccz " V "3f\n\t"                                                                            \
                 "s_cmp_lt_i32 " DR_A7 ", 0\n\t"                                                                         \
                 "s_cbranch_scc0 " V "5f\n\t"                                                                            \
                 "s_waitcnt lgkmcnt(0)\n"                                                                                \
                 V "2:\n\t"                                                                                              \
-                "s_load_dwordx8 " DR_A_ALL ", " BVH ", %[off] offset:0x20\n\t"                                          \
+                "s_load_dwordx8 " DR_A_ALL ", " BVH ", %[off] offset:0x40\n\t"                                          \
                 TESTB                                                                                                   \
-                "s_cbranch_scc0 " V "4f\n\t"                                                                            \
-                "s_add_u32 %[off], %[off], 32\n\t"                                                                      \
+                "s_cbranch_vccz " V "4f\n\t"                                                                            \
+                "s_add_u32 %[off], %[off], 64\n\t"                                                                      \
                 "s_cmp_lt_i32 " DR_B7 ", 0\n\t"                                                                         \
                 "s_cbranch_scc0 " V "6f\n\t"                                                                            \
                 "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
@@ -651,11 +705,12 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
                 "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
                 "s_branch " V "1b\n"                                                                                    \
                 V "4:\n\t"                                                                                              \
-                "s_mov_b32 %[off], " DR_B6 "\n\t"                                                                       \
-                "s_load_dwordx8 " DR_B_ALL ", " BVH ", %[off] offset:0x0\n\t"                                           \
+                "s_sub_u32 %[off], " DR_B6 ", 32\n\t"                                                                   \
+                "s_load_dwordx8 " DR_B_ALL ", " BVH ", %[off] offset:0x20\n\t"                                          \
                 "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
                 "s_branch " V "2b\n"                                                                                    \
                 V "5:\n\t"                                                                                              \
+                "s_add_u32 %[off], %[off], 32\n\t"                                                                      \
                 "s_mov_b32 %[leaf], " DR_A7 "\n\t"                                                                      \
                 "s_branch 99f\n"                                                                                        \
                 V "6:\n\t"                                                                                              \
@@ -663,12 +718,14 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
                 "s_branch 99f\n"
 #define DR_WALK_OCTANT(V, SX, SY, SZ)                                                                                   \
         DR_WALK_VARIANT(V, "%[bvhlh]",                                                                                  \
-                DR_NODE_TEST_S(DR_SEL(SX, DR_A0, DR_A3), DR_SEL(SY, DR_A1, DR_A4), DR_SEL(SZ, DR_A2, DR_A5),            \
+                DR_NODE_TEST_SX(DR_SEL(SX, DR_A0, DR_A3), DR_SEL(SY, DR_A1, DR_A4), DR_SEL(SZ, DR_A2, DR_A5),            \
                                DR_SEL(SX, DR_A3, DR_A0), DR_SEL(SY, DR_A4, DR_A1), DR_SEL(SZ, DR_A5, DR_A2)),           \
-                DR_NODE_TEST_S(DR_SEL(SX, DR_B0, DR_B3), DR_SEL(SY, DR_B1, DR_B4), DR_SEL(SZ, DR_B2, DR_B5),            \
+                DR_NODE_TEST_SX(DR_SEL(SX, DR_B0, DR_B3), DR_SEL(SY, DR_B1, DR_B4), DR_SEL(SZ, DR_B2, DR_B5),           \
                                DR_SEL(SX, DR_B3, DR_B0), DR_SEL(SY, DR_B4, DR_B1), DR_SEL(SZ, DR_B5, DR_B2)))
 #define DR_WALK_ASM_OCTANTS                                                                                             \
             asm volatile(                                                                                               \
+                "s_mov_b64 %[sexec], exec\n\t"                                                                          \
+                "s_mov_b64 exec, %[alive]\n\t"                                                                          \
                 "s_cmp_gt_u32 %[oct], 7\n\t"                                                                            \
                 "s_cbranch_scc1 80f\n\t"                                                                                \
                 "s_bitcmp1_b32 %[oct], 2\n\t"                                                                           \
@@ -700,14 +757,15 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
                 DR_WALK_OCTANT("5", 1, 0, 1)                                                                            \
                 DR_WALK_OCTANT("6", 0, 1, 1)                                                                            \
                 DR_WALK_OCTANT("7", 1, 1, 1)                                                                            \
-                DR_WALK_VARIANT("8", "%[bvh]", DR_NODE_TEST(DR_A0, DR_A1, DR_A2, DR_A3, DR_A4, DR_A5),                  \
-                                DR_NODE_TEST(DR_B0, DR_B1, DR_B2, DR_B3, DR_B4, DR_B5))                                 \
+                DR_WALK_VARIANT("8", "%[bvh]", DR_NODE_TEST_X(DR_A0, DR_A1, DR_A2, DR_A3, DR_A4, DR_A5),                \
+                                DR_NODE_TEST_X(DR_B0, DR_B1, DR_B2, DR_B3, DR_B4, DR_B5))                               \
                 "99:\n\t"                                                                                               \
+                "s_mov_b64 exec, %[sexec]\n\t"                                                                          \
                 "s_waitcnt lgkmcnt(0)"                                                                                  \
-                : [off] "+s"(off), [leaf] "=s"(leaf), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),   \
+                : [off] "+s"(off), [leaf] "=s"(leaf), [sexec] "=&s"(sexec), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),   \
                   [t4] "=&v"(t4), [t5] "=&v"(t5)                                                                        \
                 : [bvh] "s"(bvh), [bvhlh] "s"(bvh_lh), [oct] "s"(octant), [alive] "s"(alive_m), [kx] "v"(kk.x), [ky] "v"(kk.y),    \
-                  [kz] "v"(kk.z), [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z), [tmax] "v"(tmax)                      \
+                  [kz] "v"(kk.z), [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z), [tmax] "v"(tmax_w)                    \
                 : DR_WALK_CLOBBERS, "vcc", "scc")
 #define DR_WALK_ASM(CHECK)                                                                                              \
             asm volatile(                                                                                               \
@@ -755,7 +813,7 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
                 : [off] "+s"(off), [leaf] "=s"(leaf), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),   \
                   [t4] "=&v"(t4), [t5] "=&v"(t5)                                                                        \
                 : [bvh] "s"(bvh), [alive] "s"(alive_m), [end] "s"(end), [kx] "v"(kk.x), [ky] "v"(kk.y), [kz] "v"(kk.z), \
-                  [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z), [tmax] "v"(tmax)                                      \
+                  [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z), [tmax] "v"(tmax_w)                                    \
                 : DR_WALK_CLOBBERS, "vcc", "scc")
 
 // Walk of one RANGE [off, end) of the threaded BVH for one wave of rays (segments [0,tmax] from org along dn);
@@ -779,7 +837,7 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
 template <bool STATS, bool RANGE>
 __device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restrict__ bvh, const TriRec* __restrict__ tri_sorted,
                                                          unsigned off, const unsigned end, f3 org, f3 dn, f3 inv, f3 iv, f3 kk,
-                                                         float tmax, int hi, unsigned long long alive_m, int& n_visit, int& n_leaf,
+                                                         float tmax, float tmax_w, int hi, unsigned long long alive_m, int& n_visit, int& n_leaf,
                                                          const BvhNode* __restrict__ bvh_lh = nullptr, int octant = 8) {
     for (;;) {
         if (RANGE && off >= end) break;
@@ -793,7 +851,7 @@ __device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restri
                 const unsigned nd_skip = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
                 const int nd_leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
                 n_visit++;
-                const unsigned long long hb_m = node_hit_mask(nc, nh, iv, kk, tmax) & alive_m;
+                const unsigned long long hb_m = node_hit_mask(nc, nh, iv, kk, tmax_w) & alive_m;
                 if (hb_m == 0ull) { off = nd_skip; continue; }
                 off += 32u;
                 if (nd_leaf >= 0) { leaf = nd_leaf; break; }
@@ -806,7 +864,7 @@ __device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restri
             // without ranges there is no end compare at all: skips that leave the tree land on the sentinel node
             // (all-space box, leaf code BVH_END), which every live lane hits
             if (RANGE) { DR_WALK_ASM("s_cmp_lt_u32 %[off], %[end]\n\ts_cbranch_scc0 8f\n\t"); }
-            else { DR_WALK_ASM_OCTANTS; }
+            else { unsigned long long sexec; DR_WALK_ASM_OCTANTS; }
         }
         if (leaf == BVH_END) break;          // the range is done (or the tree's sentinel was reached)
         if (STATS) n_leaf++;
@@ -869,14 +927,14 @@ __device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restri
                 : [roff] "+s"(roff), [hit] "=s"(r_hit), [rs] "=s"(r_start), [re] "=s"(r_end), [t0] "=&v"(t0), [t1] "=&v"(t1),       \
                   [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5)                                        \
                 : [base] "s"(rbase), [alive] "s"(alive_m), [rend] "s"(rend), [kx] "v"(kk.x), [ky] "v"(kk.y), [kz] "v"(kk.z),      \
-                  [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z), [tmax] "v"(tmax)                                      \
+                  [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z), [tmax] "v"(tmax_w)                                    \
                 : DR_WALK_CLOBBERS, "vcc", "scc")
 
 template <bool STATS>
 __device__ __forceinline__ unsigned long long walk_pair(const BvhNode* __restrict__ bvh, const TriRec* __restrict__ tri_sorted,
                                                         const BvhNode* __restrict__ rec_lo, const BvhNode* __restrict__ rec_hi,
                                                         int ell, int Dl, int Dh, int leaf_lo, int leaf_hi, bool from_root,
-                                                        unsigned end_all, f3 org, f3 dn, f3 inv, f3 iv, f3 kk, float tmax, int hi,
+                                                        unsigned end_all, f3 org, f3 dn, f3 inv, f3 iv, f3 kk, float tmax, float tmax_w, int hi,
                                                         unsigned long long alive_m, int& n_visit, int& n_leaf, int& n_stream) {
     unsigned off = 0u, end = from_root ? end_all : 0u;
     int seg = from_root ? 3 : -1;                     // record segment being streamed (0..2), then 3, 4: the own leaves, 5: done
@@ -894,7 +952,7 @@ __device__ __forceinline__ unsigned long long walk_pair(const BvhNode* __restric
                     const unsigned nd_skip = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
                     const int nd_leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
                     n_visit++;
-                    const unsigned long long hb_m = node_hit_mask(nc, nh, iv, kk, tmax) & alive_m;
+                    const unsigned long long hb_m = node_hit_mask(nc, nh, iv, kk, tmax_w) & alive_m;
                     if (hb_m == 0ull) { off = nd_skip; continue; }
                     off += 32u;
                     if (nd_leaf >= 0) { leaf = nd_leaf; break; }
@@ -917,7 +975,7 @@ __device__ __forceinline__ unsigned long long walk_pair(const BvhNode* __restric
                     const float nc[3] = { raw[0], raw[1], raw[2] }, nh[3] = { raw[3], raw[4], raw[5] };
                     roff += 32u;
                     n_stream++;
-                    if ((node_hit_mask(nc, nh, iv, kk, tmax) & alive_m) != 0ull) {
+                    if ((node_hit_mask(nc, nh, iv, kk, tmax_w) & alive_m) != 0ull) {
                         r_hit = 1;
                         r_start = __builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
                         r_end = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
@@ -1286,9 +1344,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82))) void k_ff_
                 if (STATS && lo == P.dbg_lo && hi == P.dbg_hi && lane == 0) P.pairs_traced[1] = alive_m;
                 if (alive_m != 0ull) {
                     // per-ray constants of the node test
-                    const f3 iv = f3{ __builtin_amdgcn_fmed3f(inv.x, -1e18f, 1e18f), __builtin_amdgcn_fmed3f(inv.y, -1e18f, 1e18f),
-                                      __builtin_amdgcn_fmed3f(inv.z, -1e18f, 1e18f) };
+                    // (in units of 1 / t_scale, a power of two: every product below is the unscaled one times t_scale, bit for bit)
+                    const float ts = P.t_scale;
+                    const f3 iv = f3{ __builtin_amdgcn_fmed3f(inv.x, -1e18f, 1e18f) * ts, __builtin_amdgcn_fmed3f(inv.y, -1e18f, 1e18f) * ts,
+                                      __builtin_amdgcn_fmed3f(inv.z, -1e18f, 1e18f) * ts };
                     const f3 kk = f3{ -(org.x * iv.x), -(org.y * iv.y), -(org.z * iv.z) };
+                    const float tmax_w = tmax * ts;
                     // The list only serves rays that really run from tile I's box to tile J's (see "Exactness" above):
                     // one ray outside (a tmax that is rounding noise, an origin offset that leaves the box) and this
                     // pair walks from the root.
@@ -1315,19 +1376,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82))) void k_ff_
                         }
                         octant = __builtin_amdgcn_readfirstlane(octant);
                         if (STATS && octant == 8 && lane == 0 && P.dbg_lo < 0) atomicAdd(P.pairs_traced + 13, 1ull);
-                        alive_m = walk_range<STATS, false>(P.bvh, P.tri_sorted, 0u, end_all, org, dn, inv, iv, kk, tmax, hi, alive_m, n_visit, n_leaf,
+                        alive_m = walk_range<STATS, false>(P.bvh, P.tri_sorted, 0u, end_all, org, dn, inv, iv, kk, tmax, tmax_w, hi, alive_m, n_visit, n_leaf,
                                                            P.bvh_lh, octant);
                     }
                     if (PATHS) {
                         alive_m = walk_pair<STATS>(P.bvh, P.tri_sorted, rec_lo, rec_hi, ell, pDl, pDh, leaf_lo, leaf_hi, no_paths, end_all,
-                                                   org, dn, inv, iv, kk, tmax, hi, alive_m, n_visit, n_leaf, n_stream);
+                                                   org, dn, inv, iv, kk, tmax, tmax_w, hi, alive_m, n_visit, n_leaf, n_stream);
                     }
                     const int ne = !SHAFT ? 0 : (from_root ? 1 : n_list);
                     for (int e = 0; e < ne; e++) {
                         const uint2 rg = sList[e];
                         const unsigned r_off = from_root ? 0u : (unsigned)__builtin_amdgcn_readfirstlane((int)rg.x);
                         const unsigned r_end = from_root ? end_all : (unsigned)__builtin_amdgcn_readfirstlane((int)rg.y);
-                        alive_m = walk_range<STATS, true>(P.bvh, P.tri_sorted, r_off, r_end, org, dn, inv, iv, kk, tmax, hi, alive_m, n_visit, n_leaf);
+                        alive_m = walk_range<STATS, true>(P.bvh, P.tri_sorted, r_off, r_end, org, dn, inv, iv, kk, tmax, tmax_w, hi, alive_m, n_visit, n_leaf);
                         if (alive_m == 0ull) break;
                     }
                 }
