@@ -503,7 +503,7 @@ static int assemble_launch(dr_context* c, int K, float eps, int rule, int trace,
         { const char* e = getenv("DR_SHAFT_MIN"); p.shaft_min_bytes = (e ? atoi(e) : 128) * (int)sizeof(BvhNode); }
         { const char* e = getenv("DR_SHAFT_SHRINK"); p.shaft_near_shrink = e ? (float)atof(e) : 0.25f; }
         p.shaft_pad_ray = 1e-6f * c->scene_span; p.shaft_pad_node = 5e-6f * c->scene_span; p.shaft_tol = c->scene_span;
-        { int e2 = 0; std::frexp(4.0f * c->scene_span, &e2); e2 = std::min(std::max(e2, -100), 100); p.t_scale = std::ldexp(1.0f, -e2); }
+        p.ts_max = c->scene_span > 1e-19f ? std::min(1e19f / c->scene_span, 1e18f) : 1e18f;
         p.stats = getenv("DR_TILE_STATS") ? 1 : 0;
         p.dbg_lo = p.dbg_hi = -1;
         if (const char* dp = getenv("DR_DEBUG_PAIR")) { p.stats = 1; p.dbg_ray = 0; sscanf(dp, "%d,%d,%d", &p.dbg_lo, &p.dbg_hi, &p.dbg_ray); }

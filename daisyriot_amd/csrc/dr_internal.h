@@ -97,7 +97,7 @@ struct TileParams {
     // list instead of starting at the root.  shaft = 0 switches it off (every walk starts at the root).
     int shaft;
     int shaft_min_bytes;      // subtrees up to this many bytes of nodes are listed whole, never split further
-    float t_scale;            // power of two that puts every ray length below 1/4 (the walk's node tests run in these units)
+    float ts_max;             // cap of a ray's 1/length scale in the walk's node tests: 1e19 / max|coordinate| (keeps org * iv finite)
     float shaft_pad_ray;      // growth of a tile's box the rays' end points are checked against
     float shaft_pad_node;     // growth of a tile's box the shaft is built from (>= pad_ray + the node test's error)
     float shaft_tol;          // max |coordinate| + diagonal: scale of the rounding tolerance of the plane tests

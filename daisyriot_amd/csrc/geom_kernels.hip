@@ -421,6 +421,22 @@ __device__ __forceinline__ bool tri_hit(f3 o, f3 d, f3 a, f3 e1, f3 e2, float& t
     return (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t > 0.0f);
 }
 
+// The same test as a wave mask (each compare straight into an SGPR pair; predicates: 1 ==, 2 >, 3 >=, 4 <, 5 <=, ordered).
+// Same operations in the same order as tri_hit.
+__device__ __forceinline__ unsigned long long tri_hit_mask(f3 o, f3 d, f3 a, f3 e1, f3 e2, float& t_out) {
+    f3 p = cross3(d, e2);
+    float det = dot3(e1, p);
+    float inv = 1.0f / det;
+    f3 tv = o - a;
+    float u = dot3(tv, p) * inv;
+    f3 q = cross3(tv, e1);
+    float v = dot3(d, q) * inv;
+    float t = dot3(e2, q) * inv;
+    t_out = t;
+    return __builtin_amdgcn_fcmpf(u, 0.0f, 3) & __builtin_amdgcn_fcmpf(v, 0.0f, 3) & __builtin_amdgcn_fcmpf(u + v, 1.0f, 5) &
+           __builtin_amdgcn_fcmpf(t, 0.0f, 2);
+}
+
 // Conservative slab test of the segment [0,tmax] against a (padded) box held in SGPRs, as a wave
 // mask (v_cmp straight into an SGPR pair; predicate 5 = ordered <=).  t = (plane - org) * inv: the
 // subtraction first -- the cheaper plane*inv - org*inv (one fma per plane) cancels catastrophically for
@@ -592,14 +608,16 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
         const float idet = 1.0f / det;
         const f3 tv = org - ta;
         const float u = dot3(tv, pv) * idet;
-        const unsigned long long um = gm & __builtin_amdgcn_ballot_w64((u >= 0.0f) & (u <= 1.0f));
+        const unsigned long long um = gm & __builtin_amdgcn_fcmpf(u, 0.0f, 3) & __builtin_amdgcn_fcmpf(u, 1.0f, 5);
         if (um == 0ull) continue;
         const f3 qv = cross3(tv, te1);
         const float v = dot3(dn, qv) * idet;
         const float tt = dot3(te2, qv) * idet;
-        const bool h = (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (tt > 0.0f);
+        // a hit: u >= 0 (in um), v >= 0, u + v <= 1, t > 0 -- as wave masks, no booleans to materialise
+        const unsigned long long hm = um & __builtin_amdgcn_fcmpf(v, 0.0f, 3) & __builtin_amdgcn_fcmpf(u + v, 1.0f, 5) &
+                                      __builtin_amdgcn_fcmpf(tt, 0.0f, 2);
         // closest hit is not `hi`: something nearer, or an equal-t hit of lower id
-        const unsigned long long bm = gm & __builtin_amdgcn_ballot_w64(h & ((tt < tmax) | ((tt == tmax) & (tk < hi))));
+        const unsigned long long bm = hm & (__builtin_amdgcn_fcmpf(tt, tmax, 4) | (tk < hi ? __builtin_amdgcn_fcmpf(tt, tmax, 1) : 0ull));
         blocked_m |= bm;
     }
     return blocked_m;
@@ -641,10 +659,16 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
                 "v_cmp_le_f32_e32 vcc, %[t3], %[t0]\n\t"                      \
                 "s_and_b64 vcc, vcc, %[alive]\n\t"
 // The two tests as the walk from the root uses them (suffix X): EXEC holds the live rays while the walk runs, so the compare's
-// VCC needs no s_and with the liveness mask and the branch reads VCCZ; and the ray parameter is scaled by a power of two
-// (TileParams::t_scale, exact) that puts tmax below 1/2, so that the `clamp` bit on ONE near-plane fma gives max(., 0) for
-// free: max3(clamp(tn_x), tn_y, tn_z) = max(tn_x, tn_y, tn_z, 0) unless tn_x > 1 > tmax, where both forms reject.
-// 10 vector instructions (13 for the general form), no scalar one.
+// VCC needs no s_and with the liveness mask and the branch reads VCCZ; and the ray parameter is in units of the ray's own
+// length (iv, k scaled per ray by s <= 1/tmax, see k_ff_tiles), so that the VOP3 `clamp` bit does the two end clamps for free:
+//     N = max3(clamp(tn_x), tn_y, tn_z)   = max(tn_x, tn_y, tn_z, 0) unless tn_x > 1, where F <= 1 < ... rejects either way
+//     F = clamp(min3(tf_x, tf_y, tf_z))   = min(tf_x, tf_y, tf_z, 1) unless that is negative -- then F = 0 <= N
+//     accept  <=>  N < F   (strictly)
+// Strictness is what makes the second clamp safe (clamping a far value up to 0 and accepting N <= F would admit every box
+// in the quadrant behind the origin): N = F happens only for a box that ends at the origin, begins at the destination or
+// is grazed along an edge -- a PADDED box, node_pad away from every triangle gate inside it, and the pad exceeds the test's
+// rounding errors 2.5 times over, so no triangle in such a box has a gate that accepts.
+// 9 vector instructions (12 for the general form), no scalar one.
 #define DR_NODE_TEST_X(CX, CY, CZ, HX, HY, HZ)                                \
                 "v_fma_f32 %[t0], " CX ", %[ix], %[kx]\n\t"                   \
                 "v_fma_f32 %[t1], " CY ", %[iy], %[ky]\n\t"                   \
@@ -656,9 +680,8 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
                 "v_fma_f32 %[t5], " HZ ", -|%[iz]|, %[t2]\n\t"                \
                 "v_fma_f32 %[t2], " HZ ", |%[iz]|, %[t2]\n\t"                 \
                 "v_max3_f32 %[t3], %[t3], %[t4], %[t5]\n\t"                   \
-                "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t"                   \
-                "v_min_f32_e32 %[t0], %[t0], %[tmax]\n\t"                     \
-                "v_cmp_le_f32_e32 vcc, %[t3], %[t0]\n\t"
+                "v_min3_f32 %[t0], %[t0], %[t1], %[t2] clamp\n\t"             \
+                "v_cmp_lt_f32_e32 vcc, %[t3], %[t0]\n\t"
 #define DR_NODE_TEST_SX(NX, NY, NZ, FX, FY, FZ)                               \
                 "v_fma_f32 %[t3], " NX ", %[ix], %[kx] clamp\n\t"             \
                 "v_fma_f32 %[t4], " NY ", %[iy], %[ky]\n\t"                   \
@@ -667,9 +690,8 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
                 "v_fma_f32 %[t1], " FY ", %[iy], %[ky]\n\t"                   \
                 "v_fma_f32 %[t2], " FZ ", %[iz], %[kz]\n\t"                   \
                 "v_max3_f32 %[t3], %[t3], %[t4], %[t5]\n\t"                   \
-                "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t"                   \
-                "v_min_f32_e32 %[t0], %[t0], %[tmax]\n\t"                     \
-                "v_cmp_le_f32_e32 vcc, %[t3], %[t0]\n\t"
+                "v_min3_f32 %[t0], %[t0], %[t1], %[t2] clamp\n\t"             \
+                "v_cmp_lt_f32_e32 vcc, %[t3], %[t0]\n\t"
 // The sentinel-terminated walk from the root in nine variants inside ONE asm statement (one set of operands, no control
 // flow for the compiler to reason about): V = 0..7 the sign-specialised test on bvh_lh for that octant (bit a of V set:
 // the rays point towards -axis a, the near corner's coordinate a is the upper one), "8" the general test on bvh.  Local
@@ -765,7 +787,7 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
                 : [off] "+s"(off), [leaf] "=s"(leaf), [sexec] "=&s"(sexec), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),   \
                   [t4] "=&v"(t4), [t5] "=&v"(t5)                                                                        \
                 : [bvh] "s"(bvh), [bvhlh] "s"(bvh_lh), [oct] "s"(octant), [alive] "s"(alive_m), [kx] "v"(kk.x), [ky] "v"(kk.y),    \
-                  [kz] "v"(kk.z), [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z), [tmax] "v"(tmax_w)                    \
+                  [kz] "v"(kk.z), [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z)                                        \
                 : DR_WALK_CLOBBERS, "vcc", "scc")
 #define DR_WALK_ASM(CHECK)                                                                                              \
             asm volatile(                                                                                               \
@@ -1344,12 +1366,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82))) void k_ff_
                 if (STATS && lo == P.dbg_lo && hi == P.dbg_hi && lane == 0) P.pairs_traced[1] = alive_m;
                 if (alive_m != 0ull) {
                     // per-ray constants of the node test
-                    // (in units of 1 / t_scale, a power of two: every product below is the unscaled one times t_scale, bit for bit)
-                    const float ts = P.t_scale;
+                    // in units of the ray's own length: s just below 1 / tmax (never above: the walk may see the ray a little
+                    // longer, not shorter; at most ts_max = 1e19 / max|coordinate| so that org * iv stays finite), the scaled length is then 1
+                    const float ts = fminf(__builtin_amdgcn_rcpf(tmax) * 0.99999f, P.ts_max);
                     const f3 iv = f3{ __builtin_amdgcn_fmed3f(inv.x, -1e18f, 1e18f) * ts, __builtin_amdgcn_fmed3f(inv.y, -1e18f, 1e18f) * ts,
                                       __builtin_amdgcn_fmed3f(inv.z, -1e18f, 1e18f) * ts };
                     const f3 kk = f3{ -(org.x * iv.x), -(org.y * iv.y), -(org.z * iv.z) };
-                    const float tmax_w = tmax * ts;
+                    const float tmax_w = 1.0f;
                     // The list only serves rays that really run from tile I's box to tile J's (see "Exactness" above):
                     // one ray outside (a tmax that is rounding noise, an origin offset that leaves the box) and this
                     // pair walks from the root.
@@ -1369,8 +1392,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82))) void k_ff_
                         // do all live rays point into one octant?  (they run from one patch to one patch: nearly always)
                         int octant = 8;
                         if (P.bvh_lh != nullptr) {
-                            const unsigned long long nx = __builtin_amdgcn_ballot_w64(alive && dn.x < 0.0f), ny = __builtin_amdgcn_ballot_w64(alive && dn.y < 0.0f),
-                                                     nz = __builtin_amdgcn_ballot_w64(alive && dn.z < 0.0f);
+                            const unsigned long long nx = alive_m & __builtin_amdgcn_fcmpf(dn.x, 0.0f, 4), ny = alive_m & __builtin_amdgcn_fcmpf(dn.y, 0.0f, 4),
+                                                     nz = alive_m & __builtin_amdgcn_fcmpf(dn.z, 0.0f, 4);
                             if ((nx == 0ull || nx == alive_m) && (ny == 0ull || ny == alive_m) && (nz == 0ull || nz == alive_m))
                                 octant = (nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0);
                         }
