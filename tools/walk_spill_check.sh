@@ -1,6 +1,6 @@
 #!/bin/bash
 # compile the geometry kernels and report, for the default tile kernel: SGPR/VGPR/spill counts and the v_readlane count around the hand-written walk (must be 0: spill reloads there cost 9 %)
-cd /root/repo/daisyriot_amd/csrc
+mkdir -p /tmp/isa; cd $(dirname $(readlink -f $0))/../daisyriot_amd/csrc
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -Rpass-analysis=kernel-resource-usage -save-temps=obj -c geom_kernels.hip -o /tmp/isa/geom.o 2> /tmp/isa/res.txt
 grep -A12 "k_ff_tilesILi256ELb0ELi0EEE" /tmp/isa/res.txt | grep -i "TotalSGPRs\|  VGPRs:\|occupancy\|SGPRs Spill"
 cd /tmp/isa
