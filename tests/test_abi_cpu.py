@@ -123,7 +123,7 @@ def test_tile_kernel_register_budget():
     if not os.path.exists(path):
         pytest.skip("library built without the resource report")
     text = open(path).read()
-    blocks = re.split(r"remark: Function Name: ", text)[1:]
+    blocks = re.split(r"Function Name: ", text)[1:]
     tile = [b for b in blocks if b.startswith("_ZN2dr10k_ff_tilesILi256ELb0ELi0EEE")]
     assert len(tile) == 1, "default tile kernel not found in the resource report"
     def val(name):
