@@ -1287,6 +1287,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82))) void k_ff_
     __syncthreads();
     const int n_act = sCount;
     const unsigned end_all = (unsigned)P.n_nodes * (unsigned)sizeof(BvhNode);
+    // every ray starts inside the root's box: an interior root is entered without its test (the walk starts at its first child)
+    const unsigned root_off = P.n_nodes >= 3 ? (unsigned)sizeof(BvhNode) : 0u;
 
     // ---- the tile pair's shaft: the node ranges its walks run over --------------------------------
     const bool use_shaft = SHAFT && (n_act > 0) && (P.trace != 0);
@@ -1399,7 +1401,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82))) void k_ff_
                         }
                         octant = __builtin_amdgcn_readfirstlane(octant);
                         if (STATS && octant == 8 && lane == 0 && P.dbg_lo < 0) atomicAdd(P.pairs_traced + 13, 1ull);
-                        alive_m = walk_range<STATS, false>(P.bvh, P.tri_sorted, 0u, end_all, org, dn, inv, iv, kk, tmax, tmax_w, hi, alive_m, n_visit, n_leaf,
+                        alive_m = walk_range<STATS, false>(P.bvh, P.tri_sorted, root_off, end_all, org, dn, inv, iv, kk, tmax, tmax_w, hi, alive_m, n_visit, n_leaf,
                                                            P.bvh_lh, octant);
                     }
                     if (PATHS) {
