@@ -79,6 +79,33 @@ def pmc_traffic(N, S, world):
     return None, why
 
 
+def assembly_issue_profile(N, world):
+    """what bounds the assembly kernel (it is issue-bound, not HBM-bound: SURVEY.md 8d): instruction counters of k_ff_tiles from
+    committed rocprofv3 PMC passes (tools/pmc_asm3.sh) -- only when taken on this workload and on the kernel source as it is
+    now; otherwise a one-line reason."""
+    sha = hashlib.sha256(open(os.path.join(ROOT, "daisyriot_amd", "csrc", "geom_kernels.hip"), "rb").read()).hexdigest()[:16]
+    why = "no committed counter passes for this workload"
+    if world != 1:
+        return why
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_asm_64k.json")
+        try:
+            d = json.load(open(path))
+            if d["workload"]["patches"] != N:
+                continue
+            if d.get("kernel_source_sha") != sha:
+                why = "%s was taken on another version of geom_kernels.hip" % os.path.relpath(path, ROOT)
+                continue
+            return {"bound": "vector instruction issue", "source": os.path.relpath(path, ROOT), "kernel_source_sha": sha,
+                    "valu_pipe_busy": d["valu_pipe_busy"], "clock_GHz": d["clock_GHz"],
+                    "valu_instructions_per_traced_pair": d["per_traced_pair"]["valu_instructions"],
+                    "scalar_instructions_per_traced_pair": d["per_traced_pair"]["salu_and_branch_instructions"],
+                    "formula": d["valu_pipe_busy_formula"]}
+        except (OSError, KeyError, ValueError):
+            continue
+    return why
+
+
 def bare_read_gbs():
     """the best a kernel that only reads 17.18 GB reaches on this part (tools/hbm_probe.hip), from profiles/"""
     for rnd in PROFILE_ROUNDS:
@@ -424,7 +451,8 @@ def main():
                          "note": "per rank: that rank's algorithmic shard bytes / its hipEvent-timed kernel; slowest rank shown"},
             "formfactors": {"value": N * (N - 1) / t_asm, "unit": "pairs/s", "seconds": t_asm,
                             "kernel_seconds": t_asm_kernel, "bvh_build_seconds": t_bvh,
-                            "pairs_traced": pairs_traced, "rays_per_s": pairs_traced * args.rays / t_asm},
+                            "pairs_traced": pairs_traced, "rays_per_s": pairs_traced * args.rays / t_asm,
+                            "issue_profile": assembly_issue_profile(N, world)},
             "residual_sum_after_timed_passes": resid,
             "converge_mode": converge_report,
             # optional dr_solver_skip_zero_blocks: all-zero 32 x 256 blocks of F are not read (bit-identical results);

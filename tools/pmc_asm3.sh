@@ -1,5 +1,6 @@
 #!/bin/bash
-# scalar-cache and wait counters of the assembly kernel (16k patches); one counter group per run
+# instruction, scalar-cache and wait counters of the assembly kernel (NPATCH patches, default 16384); one counter group per run.
+# Writes $OUT/summary.txt and $OUT/pmc_asm.json (copy into profiles/rNN/: bench.py reports it when the kernel source matches).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_asm3
 rm -rf $OUT; mkdir -p $OUT
@@ -13,13 +14,4 @@ for grp in "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQ_WAVE_CYCLES" \
   i=$((i+1))
   timeout -k 10 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/run$i -o c -- python3 tools/asm_one.py > $OUT/run$i.log 2>&1 || { echo "group $i failed"; tail -5 $OUT/run$i.log; }
 done
-python3 - <<'PY'
-import csv, glob, collections
-tot = collections.defaultdict(float)
-for f in glob.glob("gpurun_out/pmc_asm3/run*/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "k_ff_tiles" in r["Kernel_Name"]:
-            tot[r["Counter_Name"]] = max(tot[r["Counter_Name"]], float(r["Counter_Value"]))
-pairs = 92506664.0
-for k in sorted(tot): print("%-24s %16.0f  per pair %10.1f" % (k, tot[k], tot[k]/pairs))
-PY
+python3 tools/pmc_asm.py $OUT
