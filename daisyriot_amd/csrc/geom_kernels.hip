@@ -17,6 +17,8 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <vector>
 #include <rocprim/rocprim.hpp>
 
 namespace dr {
@@ -329,6 +331,90 @@ __global__ void k_pad_tris(int N, TriRec* __restrict__ tri_sorted) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// DR_BVH=sah: the tree's TOPOLOGY from a top-down binned surface-area heuristic on the host (one thread: a data-dependent
+// recursion over at most a few hundred thousand boxes, tens of milliseconds), in the arrays k_hierarchy would have written
+// (internal nodes 0 .. N-2 with 0 the root, leaf k = N-1+k for position k of the leaf order); bounds, collapsing into leaves,
+// the pre-order threaded layout and the path records stay on the device (k_refit, k_emit, k_paths).  Any binary tree over
+// the triangles gives bit-identical results -- what is hit is decided per triangle -- the tree only decides how many nodes a
+// walk visits: the Morton tree's top nodes are octants of the scene (a room's corner: three walls in one fat box that every
+// ray through the interior enters), this one's are thin sheets.
+// ---------------------------------------------------------------------------------------
+static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, std::vector<int>& left, std::vector<int>& right,
+                               std::vector<int>& first, std::vector<int>& last, std::vector<int>& parent) {
+    constexpr int NB = 32;
+    order.resize(N); for (int i = 0; i < N; i++) order[i] = i;
+    left.assign(N > 1 ? N - 1 : 1, 0); right = left; first = left; last = left;
+    parent.assign(2 * (size_t)N - 1, -1);
+    if (N < 2) return;
+    std::vector<float> cen(3 * (size_t)N);
+    for (int i = 0; i < N; i++) for (int a = 0; a < 3; a++) cen[3 * (size_t)i + a] = 0.5f * T[i].lo[a] + 0.5f * T[i].hi[a];
+    struct Job { int b, e, id; };
+    std::vector<Job> stack; stack.push_back({ 0, N, 0 });
+    int next_internal = 1;
+    auto area = [](const float* lo, const float* hi) {
+        const float dx = std::max(hi[0] - lo[0], 0.0f), dy = std::max(hi[1] - lo[1], 0.0f), dz = std::max(hi[2] - lo[2], 0.0f);
+        return dx * dy + dy * dz + dz * dx;
+    };
+    while (!stack.empty()) {
+        const Job j = stack.back(); stack.pop_back();
+        const int n = j.e - j.b;
+        int m = j.b + n / 2;
+        if (n > 2) {
+            float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+            for (int k = j.b; k < j.e; k++) for (int a = 0; a < 3; a++) {
+                const float c = cen[3 * (size_t)order[k] + a]; clo[a] = std::min(clo[a], c); chi[a] = std::max(chi[a], c);
+            }
+            float best = INFINITY; int best_axis = -1, best_bin = 0;
+            for (int a = 0; a < 3; a++) {
+                const float ext = chi[a] - clo[a];
+                if (!(ext > 0.0f)) continue;
+                const float scale = (float)NB / ext;
+                int cnt[NB]; float blo[NB][3], bhi[NB][3];
+                for (int q = 0; q < NB; q++) { cnt[q] = 0; for (int d = 0; d < 3; d++) { blo[q][d] = INFINITY; bhi[q][d] = -INFINITY; } }
+                for (int k = j.b; k < j.e; k++) {
+                    const int t = order[k];
+                    const int q = std::min(NB - 1, (int)((cen[3 * (size_t)t + a] - clo[a]) * scale));
+                    cnt[q]++;
+                    for (int d = 0; d < 3; d++) { blo[q][d] = std::min(blo[q][d], T[t].lo[d]); bhi[q][d] = std::max(bhi[q][d], T[t].hi[d]); }
+                }
+                // right-to-left suffix boxes, then left-to-right prefix sweep
+                float rarea[NB]; int rcnt[NB];
+                { float lo3[3] = { INFINITY, INFINITY, INFINITY }, hi3[3] = { -INFINITY, -INFINITY, -INFINITY }; int c = 0;
+                  for (int q = NB - 1; q >= 1; q--) {
+                      for (int d = 0; d < 3; d++) { lo3[d] = std::min(lo3[d], blo[q][d]); hi3[d] = std::max(hi3[d], bhi[q][d]); }
+                      c += cnt[q]; rcnt[q] = c; rarea[q] = c ? area(lo3, hi3) : 0.0f;
+                  } }
+                float lo3[3] = { INFINITY, INFINITY, INFINITY }, hi3[3] = { -INFINITY, -INFINITY, -INFINITY }; int c = 0;
+                for (int q = 0; q < NB - 1; q++) {                 // split between bin q and q + 1
+                    for (int d = 0; d < 3; d++) { lo3[d] = std::min(lo3[d], blo[q][d]); hi3[d] = std::max(hi3[d], bhi[q][d]); }
+                    c += cnt[q];
+                    if (c == 0 || rcnt[q + 1] == 0) continue;
+                    const float cost = area(lo3, hi3) * (float)c + rarea[q + 1] * (float)rcnt[q + 1];
+                    if (cost < best) { best = cost; best_axis = a; best_bin = q; }
+                }
+            }
+            if (best_axis >= 0) {
+                const int a = best_axis; const float scale = (float)NB / (chi[a] - clo[a]); const float c0 = clo[a];
+                int* mid = std::partition(order.data() + j.b, order.data() + j.e, [&](int t) {
+                    return std::min(NB - 1, (int)((cen[3 * (size_t)t + a] - c0) * scale)) <= best_bin; });
+                m = (int)(mid - order.data());
+                if (m <= j.b || m >= j.e) m = j.b + n / 2;           // (cannot happen: both sides were counted non-empty)
+            }
+        }
+        first[j.id] = j.b; last[j.id] = j.e - 1;
+        int child[2];
+        const int cb[2] = { j.b, m }, ce[2] = { m, j.e };
+        for (int sde = 0; sde < 2; sde++) {
+            if (ce[sde] - cb[sde] == 1) child[sde] = N - 1 + cb[sde];
+            else { child[sde] = next_internal++; stack.push_back({ cb[sde], ce[sde], child[sde] }); }
+            parent[child[sde]] = j.id;
+        }
+        left[j.id] = child[0]; right[j.id] = child[1];
+    }
+    parent[0] = -1;
+}
+
 hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[3], const float shi[3], float node_pad,
                       BvhNode* nodes, BvhNode* nodes_lh, TriRec* tri_sorted, int* n_nodes_out, BvhNode* path_rec, PathHdr* path_hdr) {
     hipError_t e;
@@ -359,13 +445,34 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
         const int nb = (N + 255) / 256;
         const char* km = getenv("DR_BVH_KEY");
         const int key_mode = km ? atoi(km) : 0;
-        hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, st, N, tri, lo3, inv3, key_mode, keys, vals);
-        DR_TRY(hipGetLastError());
-        DR_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (unsigned int)N, 0, 64, st));
-        DR_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-        DR_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (unsigned int)N, 0, 64, st));
+        // which tree: the host's SAH topology pays from about ten thousand patches up (64k: -6.7 % assembly time for a 20 ms
+        // build; 6 - 8 k patches: the 3 ms build eats the gain), below that the device's Morton tree; DR_BVH=lbvh|sah overrides
+        const char* bm = getenv("DR_BVH");
+        const bool sah = bm ? std::strcmp(bm, "sah") == 0 : N >= 12288;
+        if (sah) {
+            std::vector<TriRec> h_tri((size_t)N);
+            DR_TRY(hipMemcpyAsync(h_tri.data(), tri, sizeof(TriRec) * (size_t)N, hipMemcpyDeviceToHost, st));
+            DR_TRY(hipStreamSynchronize(st));
+            std::vector<int> h_order, h_left, h_right, h_first, h_last, h_parent;
+            sah_hierarchy_host(N, h_tri.data(), h_order, h_left, h_right, h_first, h_last, h_parent);
+            DR_TRY(hipMemcpyAsync(vals2, h_order.data(), sizeof(int) * (size_t)N, hipMemcpyHostToDevice, st));
+            if (N > 1) {
+                DR_TRY(hipMemcpyAsync(left, h_left.data(), sizeof(int) * (size_t)(N - 1), hipMemcpyHostToDevice, st));
+                DR_TRY(hipMemcpyAsync(right, h_right.data(), sizeof(int) * (size_t)(N - 1), hipMemcpyHostToDevice, st));
+                DR_TRY(hipMemcpyAsync(first, h_first.data(), sizeof(int) * (size_t)(N - 1), hipMemcpyHostToDevice, st));
+                DR_TRY(hipMemcpyAsync(last, h_last.data(), sizeof(int) * (size_t)(N - 1), hipMemcpyHostToDevice, st));
+            }
+            DR_TRY(hipMemcpyAsync(parent, h_parent.data(), sizeof(int) * nn, hipMemcpyHostToDevice, st));
+            DR_TRY(hipStreamSynchronize(st));               // (the host vectors go out of scope)
+        } else {
+            hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, st, N, tri, lo3, inv3, key_mode, keys, vals);
+            DR_TRY(hipGetLastError());
+            DR_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (unsigned int)N, 0, 64, st));
+            DR_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+            DR_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (unsigned int)N, 0, 64, st));
+        }
         DR_TRY(hipMemsetAsync(flags, 0, sizeof(int) * N, st));
-        if (N > 1) {
+        if (N > 1 && !sah) {
             hipLaunchKernelGGL(k_hierarchy, dim3(nb), dim3(256), 0, st, N, keys2, left, right, first, last, parent);
             DR_TRY(hipGetLastError());
         }

@@ -732,18 +732,25 @@ def test_group_one_process_several_ranks(world, S, n, uv50):
         assert np.allclose(Bc, Bc1, rtol=2e-6, atol=1e-12)
 
 
-@pytest.mark.parametrize("mode", ["shaft", "paths", "general-node-test"])
+@pytest.mark.parametrize("mode", ["shaft", "paths", "general-node-test", "sah-tree", "morton-tree", "sah-tree+paths"])
 def test_alternative_walks_are_exact(mode, uv50, monkeypatch):
     """The walks that are built, exact and not shipped as the default (profiles/r02/assembly_notes.md) -- DR_SHAFT=1: tile-pair
-    shaft lists; DR_PATHS=1: per-patch path records; DR_OCTANT=0: the general node test for every pair -- give the same ray
+    shaft lists; DR_PATHS=1: per-patch path records; DR_OCTANT=0: the general node test for every pair -- and the two trees
+    (DR_BVH=sah: topology from the host's binned SAH, DR_BVH=lbvh: the device's Morton tree) give the same ray
     counts and F as the brute-force oracle: on a soup far from the origin, on the Cornell box, and with an origin offset that
     throws rays out of their tile's box (shaft lists: those pairs walk from the root)"""
     if mode == "shaft":
         monkeypatch.setenv("DR_SHAFT", "1")
     elif mode == "paths":
         monkeypatch.setenv("DR_PATHS", "1")
-    else:
+    elif mode == "general-node-test":
         monkeypatch.setenv("DR_OCTANT", "0")
+    elif mode == "sah-tree":          # the host's SAH topology (the default from 12 288 patches up) on these small scenes
+        monkeypatch.setenv("DR_BVH", "sah")
+    elif mode == "morton-tree":
+        monkeypatch.setenv("DR_BVH", "lbvh")
+    else:
+        monkeypatch.setenv("DR_BVH", "sah"); monkeypatch.setenv("DR_PATHS", "1")
     for mn in (("8", "128") if mode == "shaft" else ("128",)):
         monkeypatch.setenv("DR_SHAFT_MIN", mn)
         rs = np.random.RandomState(5)

@@ -9,4 +9,4 @@ c = api.Context(0)
 c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
 c.assemble(uv)
 i = c.info()
-print("RES", N, "ms", round(i.last_assemble_ms,1), "traced", i.pairs_traced, flush=True)
+print("RES", N, "ms", round(i.last_assemble_ms,1), "traced", i.pairs_traced, "bvh_ms", round(i.last_bvh_ms,2), flush=True)
