@@ -449,9 +449,11 @@ def main():
                          "frac_of_bare_read": achieved / bare if bare else None,
                          "launches_timed": int(info.sweep_launches), "per_rank": per_rank,
                          "note": "per rank: that rank's algorithmic shard bytes / its hipEvent-timed kernel; slowest rank shown"},
-            "formfactors": {"value": N * (N - 1) / t_asm, "unit": "pairs/s", "seconds": t_asm,
+            # seconds = the BVH build (inside dr_scene_set_mesh: tree topology on the host, bounds and layout on the device)
+            # + dr_formfactors_assemble, as SURVEY.md 8(d) defines t_assemble
+            "formfactors": {"value": N * (N - 1) / (t_asm + t_bvh), "unit": "pairs/s", "seconds": t_asm + t_bvh,
                             "kernel_seconds": t_asm_kernel, "bvh_build_seconds": t_bvh,
-                            "pairs_traced": pairs_traced, "rays_per_s": pairs_traced * args.rays / t_asm,
+                            "pairs_traced": pairs_traced, "rays_per_s": pairs_traced * args.rays / (t_asm + t_bvh),
                             "issue_profile": assembly_issue_profile(N, world)},
             "residual_sum_after_timed_passes": resid,
             "converge_mode": converge_report,

@@ -342,7 +342,9 @@ __global__ void k_pad_tris(int N, TriRec* __restrict__ tri_sorted) {
 // ---------------------------------------------------------------------------------------
 static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, std::vector<int>& left, std::vector<int>& right,
                                std::vector<int>& first, std::vector<int>& last, std::vector<int>& parent) {
-    constexpr int NB = 32;
+    constexpr int NBMAX = 128;
+    const char* nbe = getenv("DR_SAH_BINS");
+    const int NB = nbe ? std::min(std::max(atoi(nbe), 2), NBMAX) : 32;
     order.resize(N); for (int i = 0; i < N; i++) order[i] = i;
     left.assign(N > 1 ? N - 1 : 1, 0); right = left; first = left; last = left;
     parent.assign(2 * (size_t)N - 1, -1);
@@ -352,8 +354,14 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
     struct Job { int b, e, id; };
     std::vector<Job> stack; stack.push_back({ 0, N, 0 });
     int next_internal = 1;
-    auto area = [](const float* lo, const float* hi) {
-        const float dx = std::max(hi[0] - lo[0], 0.0f), dy = std::max(hi[1] - lo[1], 0.0f), dz = std::max(hi[2] - lo[2], 0.0f);
+    // the "rays" are bundles (a pair's 50 rays: about one patch wide at both ends): a bundle meets a box with a probability
+    // that goes with the area of the box grown by the bundle's radius -- DR_SAH_DILATE x the mean patch-box diagonal
+    double dsum = 0.0;
+    for (int i = 0; i < N; i++) { double q = 0; for (int a = 0; a < 3; a++) { const double d = (double)T[i].hi[a] - T[i].lo[a]; q += d * d; } dsum += std::sqrt(q); }
+    const char* dle = getenv("DR_SAH_DILATE");
+    const float grow = (dle ? (float)atof(dle) : 0.5f) * (float)(dsum / N);      // (0 -> 0.5: 78.7 -> 77.6 node visits per pair)
+    auto area = [grow](const float* lo, const float* hi) {
+        const float dx = std::max(hi[0] - lo[0], 0.0f) + grow, dy = std::max(hi[1] - lo[1], 0.0f) + grow, dz = std::max(hi[2] - lo[2], 0.0f) + grow;
         return dx * dy + dy * dz + dz * dx;
     };
     while (!stack.empty()) {
@@ -370,7 +378,7 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
                 const float ext = chi[a] - clo[a];
                 if (!(ext > 0.0f)) continue;
                 const float scale = (float)NB / ext;
-                int cnt[NB]; float blo[NB][3], bhi[NB][3];
+                int cnt[NBMAX]; float blo[NBMAX][3], bhi[NBMAX][3];
                 for (int q = 0; q < NB; q++) { cnt[q] = 0; for (int d = 0; d < 3; d++) { blo[q][d] = INFINITY; bhi[q][d] = -INFINITY; } }
                 for (int k = j.b; k < j.e; k++) {
                     const int t = order[k];
@@ -379,7 +387,7 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
                     for (int d = 0; d < 3; d++) { blo[q][d] = std::min(blo[q][d], T[t].lo[d]); bhi[q][d] = std::max(bhi[q][d], T[t].hi[d]); }
                 }
                 // right-to-left suffix boxes, then left-to-right prefix sweep
-                float rarea[NB]; int rcnt[NB];
+                float rarea[NBMAX]; int rcnt[NBMAX];
                 { float lo3[3] = { INFINITY, INFINITY, INFINITY }, hi3[3] = { -INFINITY, -INFINITY, -INFINITY }; int c = 0;
                   for (int q = NB - 1; q >= 1; q--) {
                       for (int d = 0; d < 3; d++) { lo3[d] = std::min(lo3[d], blo[q][d]); hi3[d] = std::max(hi3[d], bhi[q][d]); }
