@@ -906,20 +906,22 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
                 : DR_WALK_CLOBBERS, "vcc", "scc")
 #define DR_WALK_ASM(CHECK)                                                                                              \
             asm volatile(                                                                                               \
+                "s_mov_b64 %[sexec], exec\n\t"                                                                          \
+                "s_mov_b64 exec, %[alive]\n\t"                                                                          \
                 "s_load_dwordx8 " DR_A_ALL ", %[bvh], %[off] offset:0x0\n\t"                                            \
                 "s_waitcnt lgkmcnt(0)\n"                                                                                \
                 "1:\n\t"                                                                                                \
                 "s_load_dwordx8 " DR_B_ALL ", %[bvh], %[off] offset:0x20\n\t"                                           \
-                DR_NODE_TEST(DR_A0, DR_A1, DR_A2, DR_A3, DR_A4, DR_A5)                                                  \
-                "s_cbranch_scc0 3f\n\t"                                                                                 \
+                DR_NODE_TEST_X(DR_A0, DR_A1, DR_A2, DR_A3, DR_A4, DR_A5)                                                \
+                "s_cbranch_vccz 3f\n\t"                                                                                 \
                 "s_add_u32 %[off], %[off], 32\n\t"                                                                      \
                 "s_cmp_lt_i32 " DR_A7 ", 0\n\t"                                                                         \
                 "s_cbranch_scc0 5f\n\t"                                                                                 \
                 "s_waitcnt lgkmcnt(0)\n"                                                                                \
                 "2:\n\t"                                                                                                \
                 "s_load_dwordx8 " DR_A_ALL ", %[bvh], %[off] offset:0x20\n\t"                                           \
-                DR_NODE_TEST(DR_B0, DR_B1, DR_B2, DR_B3, DR_B4, DR_B5)                                                  \
-                "s_cbranch_scc0 4f\n\t"                                                                                 \
+                DR_NODE_TEST_X(DR_B0, DR_B1, DR_B2, DR_B3, DR_B4, DR_B5)                                                \
+                "s_cbranch_vccz 4f\n\t"                                                                                 \
                 "s_add_u32 %[off], %[off], 32\n\t"                                                                      \
                 "s_cmp_lt_i32 " DR_B7 ", 0\n\t"                                                                         \
                 "s_cbranch_scc0 6f\n\t"                                                                                 \
@@ -946,11 +948,12 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
                 "8:\n\t"                                                                                                \
                 "s_mov_b32 %[leaf], 0x7ffffff8\n"                                                                       \
                 "7:\n\t"                                                                                                \
+                "s_mov_b64 exec, %[sexec]\n\t"                                                                          \
                 "s_waitcnt lgkmcnt(0)"                                                                                  \
-                : [off] "+s"(off), [leaf] "=s"(leaf), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),   \
+                : [off] "+s"(off), [leaf] "=s"(leaf), [sexec] "=&s"(sexec), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),   \
                   [t4] "=&v"(t4), [t5] "=&v"(t5)                                                                        \
                 : [bvh] "s"(bvh), [alive] "s"(alive_m), [end] "s"(end), [kx] "v"(kk.x), [ky] "v"(kk.y), [kz] "v"(kk.z), \
-                  [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z), [tmax] "v"(tmax_w)                                    \
+                  [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z)                                                        \
                 : DR_WALK_CLOBBERS, "vcc", "scc")
 
 // Walk of one RANGE [off, end) of the threaded BVH for one wave of rays (segments [0,tmax] from org along dn);
@@ -1000,8 +1003,9 @@ __device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restri
             // into the other set; a miss reloads its own set from the skip offset (RANGE: unless that leaves the range).
             // without ranges there is no end compare at all: skips that leave the tree land on the sentinel node
             // (all-space box, leaf code BVH_END), which every live lane hits
+            unsigned long long sexec;
             if (RANGE) { DR_WALK_ASM("s_cmp_lt_u32 %[off], %[end]\n\ts_cbranch_scc0 8f\n\t"); }
-            else { unsigned long long sexec; DR_WALK_ASM_OCTANTS; }
+            else { DR_WALK_ASM_OCTANTS; }
         }
         if (leaf == BVH_END) break;          // the range is done (or the tree's sentinel was reached)
         if (STATS) n_leaf++;
@@ -1027,20 +1031,22 @@ __device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restri
 // triangle).
 #define DR_STREAM_ASM                                                                                                   \
             asm volatile(                                                                                               \
+                "s_mov_b64 %[sexec], exec\n\t"                                                                          \
+                "s_mov_b64 exec, %[alive]\n\t"                                                                          \
                 "s_load_dwordx8 " DR_A_ALL ", %[base], %[roff] offset:0x0\n\t"                                          \
                 "s_waitcnt lgkmcnt(0)\n"                                                                                \
                 "1:\n\t"                                                                                                \
                 "s_load_dwordx8 " DR_B_ALL ", %[base], %[roff] offset:0x20\n\t"                                         \
-                DR_NODE_TEST(DR_A0, DR_A1, DR_A2, DR_A3, DR_A4, DR_A5)                                                  \
-                "s_cbranch_scc1 5f\n\t"                                                                                 \
+                DR_NODE_TEST_X(DR_A0, DR_A1, DR_A2, DR_A3, DR_A4, DR_A5)                                                \
+                "s_cbranch_vccnz 5f\n\t"                                                                                 \
                 "s_add_u32 %[roff], %[roff], 32\n\t"                                                                    \
                 "s_cmp_lt_u32 %[roff], %[rend]\n\t"                                                                     \
                 "s_cbranch_scc0 8f\n\t"                                                                                 \
                 "s_waitcnt lgkmcnt(0)\n"                                                                                \
                 "2:\n\t"                                                                                                \
                 "s_load_dwordx8 " DR_A_ALL ", %[base], %[roff] offset:0x20\n\t"                                         \
-                DR_NODE_TEST(DR_B0, DR_B1, DR_B2, DR_B3, DR_B4, DR_B5)                                                  \
-                "s_cbranch_scc1 6f\n\t"                                                                                 \
+                DR_NODE_TEST_X(DR_B0, DR_B1, DR_B2, DR_B3, DR_B4, DR_B5)                                                \
+                "s_cbranch_vccnz 6f\n\t"                                                                                 \
                 "s_add_u32 %[roff], %[roff], 32\n\t"                                                                    \
                 "s_cmp_lt_u32 %[roff], %[rend]\n\t"                                                                     \
                 "s_cbranch_scc0 8f\n\t"                                                                                 \
@@ -1060,11 +1066,12 @@ __device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restri
                 "8:\n\t"                                                                                                \
                 "s_mov_b32 %[hit], 0\n"                                                                                 \
                 "7:\n\t"                                                                                                \
+                "s_mov_b64 exec, %[sexec]\n\t"                                                                          \
                 "s_waitcnt lgkmcnt(0)"                                                                                  \
-                : [roff] "+s"(roff), [hit] "=s"(r_hit), [rs] "=s"(r_start), [re] "=s"(r_end), [t0] "=&v"(t0), [t1] "=&v"(t1),       \
+                : [roff] "+s"(roff), [sexec] "=&s"(sexec), [hit] "=s"(r_hit), [rs] "=s"(r_start), [re] "=s"(r_end), [t0] "=&v"(t0), [t1] "=&v"(t1),       \
                   [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5)                                        \
                 : [base] "s"(rbase), [alive] "s"(alive_m), [rend] "s"(rend), [kx] "v"(kk.x), [ky] "v"(kk.y), [kz] "v"(kk.z),      \
-                  [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z), [tmax] "v"(tmax_w)                                    \
+                  [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z)                                                        \
                 : DR_WALK_CLOBBERS, "vcc", "scc")
 
 template <bool STATS>
@@ -1096,6 +1103,7 @@ __device__ __forceinline__ unsigned long long walk_pair(const BvhNode* __restric
                 }
             } else {
                 float t0, t1, t2, t3, t4, t5;
+                unsigned long long sexec;
                 // (wave-uniform by construction; said explicitly for the compiler's divergence analysis)
                 off = (unsigned)__builtin_amdgcn_readfirstlane((int)off);
                 end = (unsigned)__builtin_amdgcn_readfirstlane((int)end);
@@ -1121,6 +1129,7 @@ __device__ __forceinline__ unsigned long long walk_pair(const BvhNode* __restric
                 }
             } else {
                 float t0, t1, t2, t3, t4, t5;
+                unsigned long long sexec;
                 DR_STREAM_ASM;
             }
             if (!r_hit) continue;                                   // segment exhausted
