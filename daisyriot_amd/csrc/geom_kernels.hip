@@ -398,6 +398,7 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
                     for (int d = 0; d < 3; d++) { lo3[d] = std::min(lo3[d], blo[q][d]); hi3[d] = std::max(hi3[d], bhi[q][d]); }
                     c += cnt[q];
                     if (c == 0 || rcnt[q + 1] == 0) continue;
+                    if (n > 64 && (long long)std::min(c, rcnt[q + 1]) * 32 < n) continue;   // (keeps the depth, and the build's cost, logarithmic)
                     const float cost = area(lo3, hi3) * (float)c + rarea[q + 1] * (float)rcnt[q + 1];
                     if (cost < best) { best = cost; best_axis = a; best_bin = q; }
                 }
@@ -408,6 +409,13 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
                     return std::min(NB - 1, (int)((cen[3 * (size_t)t + a] - c0) * scale)) <= best_bin; });
                 m = (int)(mid - order.data());
                 if (m <= j.b || m >= j.e) m = j.b + n / 2;           // (cannot happen: both sides were counted non-empty)
+            } else {
+                // no admissible plane (all centroids in one bin, or only lopsided cuts): the median along the longest axis
+                int a = 0;
+                for (int d = 1; d < 3; d++) if (chi[d] - clo[d] > chi[a] - clo[a]) a = d;
+                if (chi[a] - clo[a] > 0.0f)
+                    std::nth_element(order.begin() + j.b, order.begin() + m, order.begin() + j.e,
+                                     [&](int x, int y) { return cen[3 * (size_t)x + a] < cen[3 * (size_t)y + a]; });
             }
         }
         first[j.id] = j.b; last[j.id] = j.e - 1;

@@ -732,6 +732,30 @@ def test_group_one_process_several_ranks(world, S, n, uv50):
         assert np.allclose(Bc, Bc1, rtol=2e-6, atol=1e-12)
 
 
+def test_sah_tree_on_degenerate_layouts(uv50, monkeypatch):
+    """The host's SAH build on inputs that defeat binning: triangles strung along a line at exponentially growing distances (every
+    cut is lopsided) and a pile of coincident triangles (all centroids in one bin) -- the median fallback keeps the tree
+    logarithmic, and the ray counts and F still equal the brute-force oracle's."""
+    monkeypatch.setenv("DR_BVH", "sah")
+    rs = np.random.RandomState(11)
+    base = (rs.random_sample((1, 3, 3)) - 0.5).astype(np.float64)
+    line = np.concatenate([base + np.array([[[1.35 ** k, 0.0, 0.3 * (k % 3)]]]) for k in range(60)])
+    pile = np.repeat(base + np.array([[[2.0, 1.0, 0.0]]]), 90, axis=0)
+    facing = (rs.random_sample((100, 3, 3)) - 0.5) * 0.8 + np.array([[[3.0, 0.5, 2.0]]])
+    tri = np.concatenate([line, pile, facing])
+    n = tri.shape[0]
+    v = tri.reshape(-1, 3).astype(np.float32)
+    tv = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    nrm = rs.normal(size=(8, 3)).astype(np.float32)
+    tn = rs.randint(0, 8, size=(n, 3)).astype(np.int32)
+    with api.Context(0) as c:
+        c.set_mesh(v, nrm, tv, tn)
+        c.assemble(uv50, keep_visibility=True)
+        vis, F = c.read_visibility(0, n), c.read_rows(0, n)
+    Fo, viso, _ = ob.assemble_rows(ob.Mesh(v, nrm, tv, tn), uv50, bvh=False)
+    assert np.array_equal(vis, viso) and np.array_equal(_bits(F), _bits(Fo))
+
+
 def test_both_trees_give_the_same_matrix_at_16k(uv50, monkeypatch):
     """The tree only decides how many nodes a walk visits, never what is hit: the Morton tree built on the device and the SAH
     topology built on the host (the default at this size) give the same ray counts and the same F, bit for bit, on every row
