@@ -115,6 +115,7 @@ struct dr_context {
     bool manual_exchange = false;
     // measurement
     double last_assemble_ms = 0, last_bvh_ms = 0;
+    SahTopology* shared_sah = nullptr;   // set by a group around dr_group_set_mesh: one host build for all its devices
     unsigned long long pairs_traced = 0, stat_visits = 0, stat_leaves = 0;
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -420,7 +421,8 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     EventPair ev;
     HIPCHK(ev.create());
     HIPCHK(hipEventRecord(ev.a, c->stream));
-    hipError_t be = build_lbvh(c->stream, N, c->d_tri, lo, hi, node_pad, c->d_bvh, c->d_bvh_lh, c->d_tri_sorted, &c->n_nodes, c->d_path_rec, c->d_path_hdr);
+    hipError_t be = build_lbvh(c->stream, N, c->d_tri, lo, hi, node_pad, c->d_bvh, c->d_bvh_lh, c->d_tri_sorted, &c->n_nodes, c->d_path_rec, c->d_path_hdr,
+                               c->shared_sah);
     if (be != hipSuccess) return fail(DR_ERR_DEVICE, "LBVH build failed: %s", hipGetErrorString(be));
     HIPCHK(hipEventRecord(ev.b, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1111,8 +1113,15 @@ int dr_group_context(dr_group* g, int rank, dr_context** out) {
 
 int dr_group_set_mesh(dr_group* g, const float* vertices, int V, const float* normals, int Nn, const int32_t* tv, const int32_t* tn, int N) {
     GRP(g);
-    for (dr_context* c : g->ctx) { int rc = dr_scene_set_mesh(c, vertices, V, normals, Nn, tv, tn, N); if (rc) return rc; }
-    return DR_OK;
+    SahTopology topo;                    // the same mesh on every device: the host's tree topology is built once
+    int rc = DR_OK;
+    for (dr_context* c : g->ctx) {
+        c->shared_sah = &topo;
+        rc = dr_scene_set_mesh(c, vertices, V, normals, Nn, tv, tn, N);
+        c->shared_sah = nullptr;
+        if (rc) break;
+    }
+    return rc;
 }
 
 int dr_group_assemble(dr_group* g, const float* uv, int K, float eps, int rule, int keep_vis) {

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <vector>
 
 namespace dr {
 
@@ -154,11 +155,18 @@ struct SweepParams {
 // launchers implemented in the .hip files
 hipError_t launch_patch_records(hipStream_t st, int N, const float* vtx, const float* nrm,
                                 const int* tv, const int* tn, float box_pad, PatchRec* patch, TriRec* tri);
+// The host's SAH topology of one mesh (sah_hierarchy_host), kept by a group so that its contexts -- which all get the same
+// mesh -- build it once instead of once per device.
+struct SahTopology {
+    int N = -1;
+    std::vector<int> order, left, right, first, last, parent;
+};
 hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float scene_lo[3],
                       const float scene_hi[3], float node_pad, BvhNode* nodes /* room for 2N */,
                       BvhNode* nodes_lh /* the same in lower / upper corner form */,
                       TriRec* tri_sorted /* N + LEAF_MAX */, int* n_nodes_out,
-                      BvhNode* path_rec /* N * PATH_RECS */, PathHdr* path_hdr /* N */);
+                      BvhNode* path_rec /* N * PATH_RECS */, PathHdr* path_hdr /* N */,
+                      SahTopology* shared = nullptr /* N == this mesh's: use it; else fill it */);
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p);
 hipError_t launch_sweep(hipStream_t st, const SweepParams& p);
 int sweep_ksplit(int nrows, int S, int total_cols);

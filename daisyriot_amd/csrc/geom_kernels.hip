@@ -432,7 +432,8 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
 }
 
 hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[3], const float shi[3], float node_pad,
-                      BvhNode* nodes, BvhNode* nodes_lh, TriRec* tri_sorted, int* n_nodes_out, BvhNode* path_rec, PathHdr* path_hdr) {
+                      BvhNode* nodes, BvhNode* nodes_lh, TriRec* tri_sorted, int* n_nodes_out, BvhNode* path_rec, PathHdr* path_hdr,
+                      SahTopology* shared) {
     hipError_t e;
     unsigned long long *keys = nullptr, *keys2 = nullptr;
     int *vals = nullptr, *vals2 = nullptr, *ibuf = nullptr;
@@ -466,11 +467,16 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
         const char* bm = getenv("DR_BVH");
         const bool sah = bm ? std::strcmp(bm, "sah") == 0 : N >= 12288;
         if (sah) {
-            std::vector<TriRec> h_tri((size_t)N);
-            DR_TRY(hipMemcpyAsync(h_tri.data(), tri, sizeof(TriRec) * (size_t)N, hipMemcpyDeviceToHost, st));
-            DR_TRY(hipStreamSynchronize(st));
-            std::vector<int> h_order, h_left, h_right, h_first, h_last, h_parent;
-            sah_hierarchy_host(N, h_tri.data(), h_order, h_left, h_right, h_first, h_last, h_parent);
+            SahTopology local;
+            SahTopology& T = shared ? *shared : local;
+            if (T.N != N) {
+                std::vector<TriRec> h_tri((size_t)N);
+                DR_TRY(hipMemcpyAsync(h_tri.data(), tri, sizeof(TriRec) * (size_t)N, hipMemcpyDeviceToHost, st));
+                DR_TRY(hipStreamSynchronize(st));
+                sah_hierarchy_host(N, h_tri.data(), T.order, T.left, T.right, T.first, T.last, T.parent);
+                T.N = N;
+            }
+            const std::vector<int>&h_order = T.order, &h_left = T.left, &h_right = T.right, &h_first = T.first, &h_last = T.last, &h_parent = T.parent;
             DR_TRY(hipMemcpyAsync(vals2, h_order.data(), sizeof(int) * (size_t)N, hipMemcpyHostToDevice, st));
             if (N > 1) {
                 DR_TRY(hipMemcpyAsync(left, h_left.data(), sizeof(int) * (size_t)(N - 1), hipMemcpyHostToDevice, st));
