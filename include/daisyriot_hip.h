@@ -86,8 +86,10 @@ size_t dr_residual_chunk_floats(int S, int rows_per_rank);
 /* Exactly the MeshS / SimpleMesh arrays (vs/MeshS.h:14-20, vs/Defines.h:14-23;
  * handed over today at vs/OptixPrimeFunctionality.cpp:13 and :38-44):
  * vertices 3*V, normals 3*Nn, per-triangle vertex and normal indices 3*N,
- * 0-based.  Builds the per-patch records and the on-device LBVH (replaces
- * rtpModelUpdate, vs/OptixPrimeFunctionality.cpp:43-47). */
+ * 0-based.  Builds the per-patch records and the BVH (replaces rtpModelUpdate,
+ * vs/OptixPrimeFunctionality.cpp:43-47): a Morton tree on the device, or from
+ * 12 288 patches up a SAH topology from the host with bounds and layout on the
+ * device (DR_BVH=lbvh|sah overrides; the results do not depend on the tree). */
 int dr_scene_set_mesh(dr_context* ctx, const float* vertices, int V,
                       const float* normals, int Nn,
                       const int32_t* tri_vertex_idx,
@@ -230,7 +232,8 @@ typedef struct {
     size_t ld_F;              /* leading dimension of F in floats */
     size_t bytes_F;           /* resident bytes of the F shard */
     double last_assemble_ms;  /* hipEvent time of the tile kernel(s) of the last assemble (the BVH build is last_bvh_ms) */
-    double last_bvh_ms;       /* hipEvent time of the LBVH build in dr_scene_set_mesh */
+    double last_bvh_ms;       /* time of the BVH build in dr_scene_set_mesh between two stream events: the device kernels and,
+                                 from 12 288 patches up, the host's SAH topology build in between */
     uint64_t pairs_traced;    /* unordered pairs traced by the last assemble */
     uint64_t sweep_launches;  /* profiled sweep launches since dr_profile_reset */
     double sweep_ms_total;    /* their summed hipEvent durations */
