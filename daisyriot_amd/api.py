@@ -26,7 +26,7 @@ EXPORTS = [
     "dr_solver_step", "dr_solver_converge", "dr_solver_reset", "dr_solver_read", "dr_solver_residual_sums",
     "dr_comm_unique_id", "dr_comm_init", "dr_get_info", "dr_profile_enable", "dr_profile_reset",
     "dr_synchronize", "dr_debug_read_bvh", "dr_shard_rows", "dr_residual_offset",
-    "dr_comm_manual", "dr_exchange_export", "dr_exchange_import", "dr_debug_read_array",
+    "dr_comm_manual", "dr_exchange_export", "dr_exchange_import", "dr_debug_read_array", "dr_debug_sah_topology",
     "dr_display_patch_colors", "dr_display_vertex_colors",
     "dr_formfactors_assemble_split", "dr_vis_exchange_bytes", "dr_vis_exchange_export", "dr_vis_exchange_import",
     "dr_formfactors_assemble_finish", "dr_vis_exchange_tracer", "dr_solver_skip_zero_blocks",
@@ -89,6 +89,7 @@ def load_library(path=None):
     L.dr_synchronize.argtypes = [vp]
     L.dr_debug_read_bvh.argtypes = [vp, vp, i]
     L.dr_debug_read_array.argtypes = [vp, i, vp, C.c_size_t]
+    L.dr_debug_sah_topology.argtypes = [i, vp, vp, vp, vp, vp, vp, vp]
     L.dr_comm_manual.argtypes = [vp]
     L.dr_exchange_export.argtypes = [vp, vp]
     L.dr_exchange_import.argtypes = [vp, i, vp, C.c_size_t]
@@ -176,6 +177,22 @@ def comm_unique_id():
     if rc:
         raise DaisyRiotError("dr_comm_unique_id: %s" % L.dr_last_error().decode())
     return buf
+
+
+def sah_topology(boxes):
+    """tests: the tree topology the library builds on the host for N boxes [N][6] = lo xyz, hi xyz (no device needed).
+    Returns dict(order, left, right, first, last, parent) as in include/daisyriot_hip.h."""
+    L = load_library()
+    boxes = np.ascontiguousarray(boxes, np.float32)
+    N = boxes.shape[0]
+    out = {k: np.zeros(max(N - 1, 1), np.int32) for k in ("left", "right", "first", "last")}
+    out["order"] = np.zeros(N, np.int32)
+    out["parent"] = np.zeros(2 * N - 1, np.int32)
+    rc = L.dr_debug_sah_topology(N, _p(boxes), _p(out["order"]), _p(out["left"]), _p(out["right"]), _p(out["first"]), _p(out["last"]),
+                                 _p(out["parent"]))
+    if rc:
+        raise DaisyRiotError("dr_debug_sah_topology: %s" % L.dr_last_error().decode())
+    return out
 
 
 class Context:

@@ -975,6 +975,21 @@ int dr_exchange_import(dr_context* c, int src_rank, const float* in, size_t n_fl
     return DR_OK;
 }
 
+int dr_debug_sah_topology(int N, const float* boxes, int32_t* order, int32_t* left, int32_t* right, int32_t* first, int32_t* last,
+                          int32_t* parent) {
+    if (N < 1 || !boxes || !order || !parent || (N > 1 && (!left || !right || !first || !last)))
+        return fail(DR_ERR_INVALID, "dr_debug_sah_topology: N >= 1 and every array");
+    SahTopology T;
+    sah_topology_from_boxes(N, boxes, T);
+    std::memcpy(order, T.order.data(), sizeof(int) * (size_t)N);
+    if (N > 1) {
+        std::memcpy(left, T.left.data(), sizeof(int) * (size_t)(N - 1)); std::memcpy(right, T.right.data(), sizeof(int) * (size_t)(N - 1));
+        std::memcpy(first, T.first.data(), sizeof(int) * (size_t)(N - 1)); std::memcpy(last, T.last.data(), sizeof(int) * (size_t)(N - 1));
+    }
+    std::memcpy(parent, T.parent.data(), sizeof(int) * (2 * (size_t)N - 1));
+    return DR_OK;
+}
+
 int dr_debug_read_array(dr_context* c, int which, void* out, size_t bytes) {
     CTX(c);
     const void* src = nullptr;

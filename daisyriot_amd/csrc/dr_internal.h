@@ -167,6 +167,7 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float scen
                       TriRec* tri_sorted /* N + LEAF_MAX */, int* n_nodes_out,
                       BvhNode* path_rec /* N * PATH_RECS */, PathHdr* path_hdr /* N */,
                       SahTopology* shared = nullptr /* N == this mesh's: use it; else fill it */);
+void sah_topology_from_boxes(int N, const float* boxes /* N x {lo[3], hi[3]} */, SahTopology& out);
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p);
 hipError_t launch_sweep(hipStream_t st, const SweepParams& p);
 int sweep_ksplit(int nrows, int S, int total_cols);

@@ -431,6 +431,16 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
     parent[0] = -1;
 }
 
+void sah_topology_from_boxes(int N, const float* boxes, SahTopology& out) {
+    std::vector<TriRec> T((size_t)std::max(N, 0));
+    for (int i = 0; i < N; i++) {
+        std::memset(&T[i], 0, sizeof(TriRec));
+        for (int a = 0; a < 3; a++) { T[i].lo[a] = boxes[6 * (size_t)i + a]; T[i].hi[a] = boxes[6 * (size_t)i + 3 + a]; }
+    }
+    sah_hierarchy_host(N, T.data(), out.order, out.left, out.right, out.first, out.last, out.parent);
+    out.N = N;
+}
+
 hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[3], const float shi[3], float node_pad,
                       BvhNode* nodes, BvhNode* nodes_lh, TriRec* tri_sorted, int* n_nodes_out, BvhNode* path_rec, PathHdr* path_hdr,
                       SahTopology* shared) {

@@ -251,6 +251,12 @@ int dr_debug_read_bvh(dr_context* ctx, void* out, int max_nodes);
 /* tests: raw device arrays (0 TriRec[N] original order, 1 TriRec[N+2] Morton order,
  * 3 the uploaded (u,v) samples, 4 PatchRec[N]) */
 int dr_debug_read_array(dr_context* ctx, int which, void* out, size_t bytes);
+/* tests (host only, no device needed): the SAH tree topology dr_scene_set_mesh builds on the host from 12 288 patches up,
+ * for N boxes {lo[3], hi[3]}.  order[N]: box index at each position of the leaf order; internal nodes 0 .. N-2 (0 = root)
+ * with children left[i] / right[i] (>= N-1: leaf at position id - (N-1)) covering positions first[i] .. last[i];
+ * parent[2N-1] (-1 for the root). */
+int dr_debug_sah_topology(int N, const float* boxes, int32_t* order, int32_t* left, int32_t* right,
+                          int32_t* first, int32_t* last, int32_t* parent);
 
 #ifdef __cplusplus
 }
