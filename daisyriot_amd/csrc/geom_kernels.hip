@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 #include <rocprim/rocprim.hpp>
 
@@ -351,9 +353,6 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
     if (N < 2) return;
     std::vector<float> cen(3 * (size_t)N);
     for (int i = 0; i < N; i++) for (int a = 0; a < 3; a++) cen[3 * (size_t)i + a] = 0.5f * T[i].lo[a] + 0.5f * T[i].hi[a];
-    struct Job { int b, e, id; };
-    std::vector<Job> stack; stack.push_back({ 0, N, 0 });
-    int next_internal = 1;
     // the "rays" are bundles (a pair's 50 rays: about one patch wide at both ends): a bundle meets a box with a probability
     // that goes with the area of the box grown by the bundle's radius -- DR_SAH_DILATE x the mean patch-box diagonal
     double dsum = 0.0;
@@ -364,8 +363,12 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
         const float dx = std::max(hi[0] - lo[0], 0.0f) + grow, dy = std::max(hi[1] - lo[1], 0.0f) + grow, dz = std::max(hi[2] - lo[2], 0.0f) + grow;
         return dx * dy + dy * dz + dz * dx;
     };
-    while (!stack.empty()) {
-        const Job j = stack.back(); stack.pop_back();
+    // A node over n leaves owns the block of n - 1 interior ids [id, id + n - 1): itself, then its left subtree's block, then its
+    // right subtree's -- ids, ranges and the leaf order of a subtree depend on nothing outside it, so subtrees can be built by
+    // different threads and the result is the same tree whatever the schedule.
+    struct Job { int b, e, id; };
+    // splits the node `j` (partitions order[b, e)), writes its record, returns the position of the cut
+    auto split_node = [&](const Job& j) -> int {
         const int n = j.e - j.b;
         int m = j.b + n / 2;
         if (n > 2) {
@@ -419,14 +422,41 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
             }
         }
         first[j.id] = j.b; last[j.id] = j.e - 1;
-        int child[2];
-        const int cb[2] = { j.b, m }, ce[2] = { m, j.e };
-        for (int sde = 0; sde < 2; sde++) {
-            if (ce[sde] - cb[sde] == 1) child[sde] = N - 1 + cb[sde];
-            else { child[sde] = next_internal++; stack.push_back({ cb[sde], ce[sde], child[sde] }); }
-            parent[child[sde]] = j.id;
-        }
-        left[j.id] = child[0]; right[j.id] = child[1];
+        const int nl = m - j.b, nr = j.e - m;
+        const int lc = nl == 1 ? N - 1 + j.b : j.id + 1;
+        const int rc = nr == 1 ? N - 1 + m : j.id + 1 + (nl - 1);
+        left[j.id] = lc; right[j.id] = rc; parent[lc] = j.id; parent[rc] = j.id;
+        return m;
+    };
+    auto children = [&](const Job& j, int m, std::vector<Job>& out) {
+        if (m - j.b > 1) out.push_back({ j.b, m, j.id + 1 });
+        if (j.e - m > 1) out.push_back({ m, j.e, j.id + 1 + (m - j.b - 1) });
+    };
+    auto build_subtree = [&](Job root) {
+        std::vector<Job> stack; stack.push_back(root);
+        while (!stack.empty()) { const Job j = stack.back(); stack.pop_back(); children(j, split_node(j), stack); }
+    };
+    // the top of the tree on this thread until there are enough subtrees to hand out, then one subtree per task
+    int nthreads = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* te = getenv("DR_SAH_THREADS")) nthreads = std::min(std::max(atoi(te), 1), 64);
+    if (N < 8192) nthreads = 1;
+    std::vector<Job> jobs; jobs.push_back({ 0, N, 0 });
+    while (nthreads > 1 && (int)jobs.size() < 8 * nthreads) {
+        // split the largest open subtree
+        size_t big = 0;
+        for (size_t q = 1; q < jobs.size(); q++) if (jobs[q].e - jobs[q].b > jobs[big].e - jobs[big].b) big = q;
+        if (jobs[big].e - jobs[big].b < 1024) break;
+        const Job j = jobs[big]; jobs.erase(jobs.begin() + (long)big);
+        children(j, split_node(j), jobs);
+    }
+    if (nthreads == 1) { for (const Job& j : jobs) build_subtree(j); }
+    else {
+        std::sort(jobs.begin(), jobs.end(), [](const Job& x, const Job& y) { return x.e - x.b > y.e - y.b; });     // big ones first
+        std::atomic<size_t> next(0);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; t++)
+            pool.emplace_back([&]() { for (size_t q; (q = next.fetch_add(1)) < jobs.size();) build_subtree(jobs[q]); });
+        for (std::thread& th : pool) th.join();
     }
     parent[0] = -1;
 }
