@@ -781,10 +781,12 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
         if (um == 0ull) continue;
         const f3 qv = cross3(tv, te1);
         const float v = dot3(dn, qv) * idet;
+        // ... and in three: t is only formed when some lane is inside the triangle (u >= 0 from um, v >= 0, u + v <= 1); four times
+        // out of five none is (the origin patch's neighbours, whose planes the rays leave at t = 0).  As wave masks, no booleans.
+        const unsigned long long vm = um & __builtin_amdgcn_fcmpf(v, 0.0f, 3) & __builtin_amdgcn_fcmpf(u + v, 1.0f, 5);
+        if (vm == 0ull) continue;
         const float tt = dot3(te2, qv) * idet;
-        // a hit: u >= 0 (in um), v >= 0, u + v <= 1, t > 0 -- as wave masks, no booleans to materialise
-        const unsigned long long hm = um & __builtin_amdgcn_fcmpf(v, 0.0f, 3) & __builtin_amdgcn_fcmpf(u + v, 1.0f, 5) &
-                                      __builtin_amdgcn_fcmpf(tt, 0.0f, 2);
+        const unsigned long long hm = vm & __builtin_amdgcn_fcmpf(tt, 0.0f, 2);
         // closest hit is not `hi`: something nearer, or an equal-t hit of lower id
         const unsigned long long bm = hm & (__builtin_amdgcn_fcmpf(tt, tmax, 4) | (tk < hi ? __builtin_amdgcn_fcmpf(tt, tmax, 1) : 0ull));
         blocked_m |= bm;
