@@ -770,20 +770,29 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
         const f3 ta = f3{ A[0], A[1], A[2] };
         const f3 te1 = f3{ A[3], B[0], B[1] };
         const f3 te2 = f3{ B[2], B[3], C3[0] };
-        // tri_hit in two halves: a hit needs 0 <= u and (v >= 0, u + v <= 1, hence) u <= 1 -- when no gated lane has such a u
-        // the second half (a cross product, two dot products) is not evaluated.  Same operations, same order, same result.
+        // tri_hit (same operations, same order, same values) with the division moved behind two exact exclusion tests on the
+        // NUMERATORS: u = au * fl(1/det) lies outside [0, 1] for sure when |au| > |det| (1 + 2^-21) (then |u| > 1 after both
+        // roundings, or is infinite) or when au and det differ in sign and |au| > 2^-100 |det| (then u < 0 strictly: the product
+        // cannot underflow to -0, and au = 0 -- whose u = -0 passes u >= 0 -- is never excluded); the same for v, which a hit also needs in [0, 1] (v >= 0, and u + v <= 1 with u >= 0).  Only when
+        // some gated lane survives both is 1/det formed (11 instructions) and u, v, u + v, t tested as the definition says.
         const f3 pv = cross3(dn, te2);
         const float det = dot3(te1, pv);
-        const float idet = 1.0f / det;
         const f3 tv = org - ta;
-        const float u = dot3(tv, pv) * idet;
-        const unsigned long long um = gm & __builtin_amdgcn_fcmpf(u, 0.0f, 3) & __builtin_amdgcn_fcmpf(u, 1.0f, 5);
-        if (um == 0ull) continue;
+        const float au = dot3(tv, pv);
+        const float ad = fabsf(det), m_hi = ad * 1.0000005f, m_lo = ad * 7.888609e-31f;       // (1 + 2^-21, 2^-100)
+        const unsigned long long out_u = __builtin_amdgcn_fcmpf(fabsf(au), m_hi, 2) |
+                                         (__builtin_amdgcn_ballot_w64((__float_as_int(au) ^ __float_as_int(det)) < 0) & __builtin_amdgcn_fcmpf(fabsf(au), m_lo, 2));
+        unsigned long long cm = gm & ~out_u;
+        if (cm == 0ull) continue;
         const f3 qv = cross3(tv, te1);
-        const float v = dot3(dn, qv) * idet;
-        // ... and in three: t is only formed when some lane is inside the triangle (u >= 0 from um, v >= 0, u + v <= 1); four times
-        // out of five none is (the origin patch's neighbours, whose planes the rays leave at t = 0).  As wave masks, no booleans.
-        const unsigned long long vm = um & __builtin_amdgcn_fcmpf(v, 0.0f, 3) & __builtin_amdgcn_fcmpf(u + v, 1.0f, 5);
+        const float av = dot3(dn, qv);
+        const unsigned long long out_v = __builtin_amdgcn_fcmpf(fabsf(av), m_hi, 2) |
+                                         (__builtin_amdgcn_ballot_w64((__float_as_int(av) ^ __float_as_int(det)) < 0) & __builtin_amdgcn_fcmpf(fabsf(av), m_lo, 2));
+        cm &= ~out_v;
+        if (cm == 0ull) continue;
+        const float idet = 1.0f / det;
+        const float u = au * idet, v = av * idet;
+        const unsigned long long vm = gm & __builtin_amdgcn_fcmpf(u, 0.0f, 3) & __builtin_amdgcn_fcmpf(v, 0.0f, 3) & __builtin_amdgcn_fcmpf(u + v, 1.0f, 5);
         if (vm == 0ull) continue;
         const float tt = dot3(te2, qv) * idet;
         const unsigned long long hm = vm & __builtin_amdgcn_fcmpf(tt, 0.0f, 2);
