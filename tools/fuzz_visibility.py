@@ -1,7 +1,7 @@
 """One-off fuzz of the visibility definition: random triangle soups (sizes, scales, offsets, slivers, K) on the GPU
 against the brute-force oracle (every triangle tested for every ray).  Exact equality of ray counts and F expected.
-   python tools/fuzz_visibility.py [n_scenes] [first_seed]"""
-import sys, time
+   python tools/fuzz_visibility.py [n_scenes] [first_seed]      FUZZ_SCALE_EXP=lo,hi: decimal exponents of the scene scale (-3,3)"""
+import os, sys, time
 sys.path.insert(0, '.')
 import numpy as np
 from daisyriot_amd import api, scenes
@@ -9,12 +9,13 @@ from oracle import binding as ob
 
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+SCALE_EXP = tuple(float(x) for x in os.environ.get("FUZZ_SCALE_EXP", "-3,3").split(","))
 bad = 0
 t0 = time.time()
 for seed in range(seed0, seed0 + n_scenes):
     rs = np.random.RandomState(seed)
     n = int(rs.randint(40, 420))
-    scale = float(10.0 ** rs.uniform(-3, 3))
+    scale = float(10.0 ** rs.uniform(*SCALE_EXP))
     offset = float(rs.choice([0.0, 0.0, 3.0, 250.0, -4000.0])) * scale
     K = int(rs.choice([1, 7, 32, 50, 50, 64, 100]))
     rule = int(rs.randint(0, 2))
