@@ -1,4 +1,5 @@
-// geom_kernels.hip -- per-patch records, on-device LBVH, and the fused form-factor tile
+// geom_kernels.hip -- per-patch records, the BVH build (Morton tree on the device, or SAH topology from the
+// host with bounds and layout on the device), and the fused form-factor tile
 // kernel (integrand + visibility + both F tiles written once) for gfx950.
 //
 // Compiled with -ffp-contract=off: every fp32 operation below is individually rounded, in
@@ -10,7 +11,7 @@
 //   integrand    vs/triangle_math.cpp:11-74, vs/OptixPrimeFunctionality.cpp:133-161,
 //                vs/parallellism.cu:91-151
 //   visibility   vs/OptixPrimeFunctionality.cpp:54-63, 169-218, 244-271 (closest hit must be
-//                the destination patch; OptiX Prime itself is replaced by the LBVH below)
+//                the destination patch; OptiX Prime itself is replaced by the BVH below)
 //   assembly     vs/OptixPrimeFunctionality.cpp:6-34 (both directions from the integrand) and
 //                :311-366 (reverse entry by reciprocity)
 #include "dr_internal.h"
@@ -634,11 +635,12 @@ __device__ __forceinline__ float safe_inv(float d) {
 // Conservative test of the segment [0,tmax] against a BVH NODE (centre c, half-extent h in SGPRs), as a wave mask.
 // A node test only has to be conservative -- what is hit is decided per triangle by its gate (box_hit_mask) and
 // Moller-Trumbore -- so it need not be the gate's own arithmetic, only never reject a node one of whose
-// triangles' gates accepts.  This form costs 14 vector instructions instead of 24:
-//     tc = fma(c, iv, k)            k = -(org*iv), iv = the ray's 1/d clamped to +-1e18 (per ray, once)
+// triangles' gates accepts.  The general form (this function: the counted STATS build; the hand-written loops use the same
+// arithmetic in DR_NODE_TEST / DR_NODE_TEST_X, and a sign-specialised 9-instruction variant on lower / upper corners):
+//     tc = fma(c, iv, k)            k = -(org*iv), iv = the ray's 1/d clamped to +-1e18, times the ray's scale (per ray, once)
 //     tn = fma(h, -|iv|, tc)        tf = fma(h, |iv|, tc)          per axis, no plane selection, no min/max
 //     accept  <=>  max(tn_x, tn_y, tn_z, 0) <= min(tf_x, tf_y, tf_z, tmax)
-// Its rounding errors (fma form: up to 6 ulp of (|c|+|org|+h)*|iv|) and the slack the gate test grants
+// Its rounding errors (fma form: up to 7 ulp of (|c|+|org|+h)*|iv|) and the slack the gate test grants
 // (tf*1.00001, i.e. a miss by up to 1.1e-5 of the ray length) are both bounded by a DISTANCE times |iv|, so
 // they are absorbed by growing every node box once, at build time, by
 //     node_pad = 3e-5 * scene diagonal + 4e-6 * max|coordinate|
@@ -1030,11 +1032,10 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
 //
 // The node index is wave-uniform.  The compiler's lowering of this loop spent ~20 scalar instructions per
 // node (the CU's single scalar unit serves all four SIMDs) beside the vector ones, so the interior-node
-// walk is written out by hand: one s_load_dwordx8 of the node at an SGPR byte offset, the 14-instruction
-// node test (node_hit_mask), one s_and with the liveness mask whose SCC is the branch condition, then
-// either offset += 32 (descend: the first child is the next node in pre-order) or offset = skip --
-// 7 scalar instructions for a node that is entered, 8 for one that is skipped.  The hand-written stretch
-// ends whenever a hit node is a leaf or the range is left.
+// walk is written out by hand: one s_load_dwordx8 of the node at an SGPR byte offset, the node test with EXEC = the live
+// rays (9 vector instructions when the wave's rays share an octant, 12 otherwise), a branch on VCCZ, then
+// either the next node in pre-order (the first child: already loading into the other register set) or offset = skip --
+// 4 - 5 scalar instructions per node.  The hand-written stretch ends whenever a hit node is a leaf or the range is left.
 //
 // iv / kk: the per-ray constants of the node test (the ray's 1/d clamped to +-1e18, and -(org*iv)).
 // octant: 0..7 = all live rays point into that octant (bit a set: towards -axis a), the walk from the root then uses the
