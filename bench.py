@@ -79,11 +79,18 @@ def pmc_traffic(N, S, world):
     return None, why
 
 
+def code_sha(path):
+    """hash of a source file's CODE: // comments, trailing blanks and empty lines do not count (tools/pmc_asm.py has the twin)"""
+    import re
+    lines = [re.sub(r"//.*$", "", l).rstrip() for l in open(path, encoding="utf-8", errors="replace").read().split("\n")]
+    return hashlib.sha256("\n".join(l for l in lines if l).encode()).hexdigest()[:16]
+
+
 def assembly_issue_profile(N, world):
     """what bounds the assembly kernel (it is issue-bound, not HBM-bound: SURVEY.md 8d): instruction counters of k_ff_tiles from
     committed rocprofv3 PMC passes (tools/pmc_asm3.sh) -- only when taken on this workload and on the kernel source as it is
     now; otherwise a one-line reason."""
-    sha = hashlib.sha256(open(os.path.join(ROOT, "daisyriot_amd", "csrc", "geom_kernels.hip"), "rb").read()).hexdigest()[:16]
+    sha = code_sha(os.path.join(ROOT, "daisyriot_amd", "csrc", "geom_kernels.hip"))
     why = "no committed counter passes for this workload"
     if world != 1:
         return why

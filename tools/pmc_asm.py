@@ -18,7 +18,8 @@ lines = ["%-24s %16.0f  per pair %10.1f" % (k, tot[k], tot[k] / pairs) for k in 
 open(os.path.join(out, "summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sha = hashlib.sha256(open(os.path.join(root, "daisyriot_amd", "csrc", "geom_kernels.hip"), "rb").read()).hexdigest()[:16]
+lines_ = [re.sub(r"//.*$", "", l).rstrip() for l in open(os.path.join(root, "daisyriot_amd", "csrc", "geom_kernels.hip"), encoding="utf-8", errors="replace").read().split("\n")]
+sha = hashlib.sha256("\n".join(l for l in lines_ if l).encode()).hexdigest()[:16]     # code only: comments and blank lines do not count (bench.py: code_sha)
 pp = lambda k: tot[k] / pairs if k in tot else None
 wave_qc = pp("SQ_WAVE_CYCLES")
 d = {"workload": {"patches": npatch, "rays_per_pair": 50}, "kernel": "k_ff_tiles<256,false,0>", "kernel_source_sha": sha,
