@@ -1676,12 +1676,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82))) void k_ff_
     }
 }
 
-static int tile_threads() {
-    static int nt = -1;
-    if (nt < 0) { const char* e = getenv("DR_TILE_THREADS"); nt = e ? atoi(e) : 256; }
-    return nt;
-}
-
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p) {
     dim3 grid(p.nT, p.nOwnedTiles);
     const int walk = p.shaft ? 1 : (p.path_hdr ? 2 : 0);
@@ -1693,11 +1687,8 @@ hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p) {
     }
     if (walk == 1) { hipLaunchKernelGGL((k_ff_tiles<256, false, 1>), grid, dim3(256), 0, st, p); return hipGetLastError(); }
     if (walk == 2) { hipLaunchKernelGGL((k_ff_tiles<256, false, 2>), grid, dim3(256), 0, st, p); return hipGetLastError(); }
-    switch (tile_threads()) {
-        case 512: hipLaunchKernelGGL((k_ff_tiles<512, false, 0>), grid, dim3(512), 0, st, p); break;
-        case 1024: hipLaunchKernelGGL((k_ff_tiles<1024, false, 0>), grid, dim3(1024), 0, st, p); break;
-        default: hipLaunchKernelGGL((k_ff_tiles<256, false, 0>), grid, dim3(256), 0, st, p); break;
-    }
+    // (512 and 1024 threads per workgroup -- more waves sharing a queue -- measured 5 % and 14 % slower at 64k patches)
+    hipLaunchKernelGGL((k_ff_tiles<256, false, 0>), grid, dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
