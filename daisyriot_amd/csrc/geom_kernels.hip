@@ -440,7 +440,7 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
     // the top of the tree on this thread until there are enough subtrees to hand out, then one subtree per task
     int nthreads = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* te = getenv("DR_SAH_THREADS")) nthreads = std::min(std::max(atoi(te), 1), 64);
-    if (N < 8192) nthreads = 1;
+    if (N < 2048) nthreads = 1;
     std::vector<Job> jobs; jobs.push_back({ 0, N, 0 });
     while (nthreads > 1 && (int)jobs.size() < 8 * nthreads) {
         // split the largest open subtree
@@ -503,10 +503,11 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
         const int nb = (N + 255) / 256;
         const char* km = getenv("DR_BVH_KEY");
         const int key_mode = km ? atoi(km) : 0;
-        // which tree: the host's SAH topology pays from about ten thousand patches up (64k: -6.7 % assembly time for a 20 ms
-        // build; 6 - 8 k patches: the 3 ms build eats the gain), below that the device's Morton tree; DR_BVH=lbvh|sah overrides
+        // which tree: the host's SAH topology pays from a few thousand patches up (64k: -7 % assembly time for a 10 ms build;
+        // the reference's own scenes, 6400 and 7712 patches: -5 % and break-even with a 1.2 - 1.6 ms build), below that the
+        // device's Morton tree; DR_BVH=lbvh|sah overrides
         const char* bm = getenv("DR_BVH");
-        const bool sah = bm ? std::strcmp(bm, "sah") == 0 : N >= 12288;
+        const bool sah = bm ? std::strcmp(bm, "sah") == 0 : N >= 6144;
         if (sah) {
             SahTopology local;
             SahTopology& T = shared ? *shared : local;

@@ -88,7 +88,7 @@ size_t dr_residual_chunk_floats(int S, int rows_per_rank);
  * vertices 3*V, normals 3*Nn, per-triangle vertex and normal indices 3*N,
  * 0-based.  Builds the per-patch records and the BVH (replaces rtpModelUpdate,
  * vs/OptixPrimeFunctionality.cpp:43-47): a Morton tree on the device, or from
- * 12 288 patches up a SAH topology from the host with bounds and layout on the
+ * 6 144 patches up a SAH topology from the host with bounds and layout on the
  * device (DR_BVH=lbvh|sah overrides; the results do not depend on the tree). */
 int dr_scene_set_mesh(dr_context* ctx, const float* vertices, int V,
                       const float* normals, int Nn,
@@ -233,7 +233,7 @@ typedef struct {
     size_t bytes_F;           /* resident bytes of the F shard */
     double last_assemble_ms;  /* hipEvent time of the tile kernel(s) of the last assemble (the BVH build is last_bvh_ms) */
     double last_bvh_ms;       /* time of the BVH build in dr_scene_set_mesh between two stream events: the device kernels and,
-                                 from 12 288 patches up, the host's SAH topology build in between */
+                                 from 6 144 patches up, the host's SAH topology build in between */
     uint64_t pairs_traced;    /* unordered pairs traced by the last assemble */
     uint64_t sweep_launches;  /* profiled sweep launches since dr_profile_reset */
     double sweep_ms_total;    /* their summed hipEvent durations */
@@ -251,7 +251,7 @@ int dr_debug_read_bvh(dr_context* ctx, void* out, int max_nodes);
 /* tests: raw device arrays (0 TriRec[N] original order, 1 TriRec[N+2] Morton order,
  * 3 the uploaded (u,v) samples, 4 PatchRec[N]) */
 int dr_debug_read_array(dr_context* ctx, int which, void* out, size_t bytes);
-/* tests (host only, no device needed): the SAH tree topology dr_scene_set_mesh builds on the host from 12 288 patches up,
+/* tests (host only, no device needed): the SAH tree topology dr_scene_set_mesh builds on the host from 6 144 patches up,
  * for N boxes {lo[3], hi[3]}.  order[N]: box index at each position of the leaf order; internal nodes 0 .. N-2 (0 = root)
  * with children left[i] / right[i] (>= N-1: leaf at position id - (N-1)) covering positions first[i] .. last[i];
  * parent[2N-1] (-1 for the root). */

@@ -788,7 +788,7 @@ def test_alternative_walks_are_exact(mode, uv50, monkeypatch):
         monkeypatch.setenv("DR_PATHS", "1")
     elif mode == "general-node-test":
         monkeypatch.setenv("DR_OCTANT", "0")
-    elif mode == "sah-tree":          # the host's SAH topology (the default from 12 288 patches up) on these small scenes
+    elif mode == "sah-tree":          # the host's SAH topology (the default from 6 144 patches up) on these small scenes
         monkeypatch.setenv("DR_BVH", "sah")
     elif mode == "morton-tree":
         monkeypatch.setenv("DR_BVH", "lbvh")

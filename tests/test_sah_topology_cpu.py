@@ -1,4 +1,4 @@
-"""Host logic of the BVH build (no GPU): the SAH tree topology dr_scene_set_mesh hands to the device kernels from 12 288 patches
+"""Host logic of the BVH build (no GPU): the SAH tree topology dr_scene_set_mesh hands to the device kernels from 6 144 patches
 up (daisyriot_amd/csrc/geom_kernels.hip: sah_hierarchy_host), through the library's host-only debug entry."""
 import time
 
