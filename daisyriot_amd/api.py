@@ -5,7 +5,9 @@ C ABI.  There is no CPU fallback -- if the HIP library is missing or a call
 fails, an exception is raised.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -34,6 +36,7 @@ EXPORTS = [
     "dr_group_create", "dr_group_destroy", "dr_group_info", "dr_group_context", "dr_group_set_mesh",
     "dr_group_assemble", "dr_group_solver_init", "dr_group_solver_step", "dr_group_solver_converge",
     "dr_group_solver_reset", "dr_group_solver_read", "dr_group_synchronize",
+    "dr_comm_set_library", "dr_comm_library_info",
 ]
 
 
@@ -52,6 +55,26 @@ class Info(C.Structure):
 _lib = None
 
 
+def _torch_rocm_dir():
+    """torch/lib of an installed torch-ROCm wheel, found WITHOUT importing torch (None: no torch, or DR_SYSTEM_ROCM=1).
+
+    The wheel bundles its own HIP runtime and RCCL and loads them by FILE name (NEEDED libamdhip64.so / librccl.so), which the
+    loader does not match with the system copies this library would otherwise pull in by SONAME: a process that loads
+    libdaisyriot_hip.so first and imports torch later ends up with two HIP runtimes and two RCCLs.  So in a Python process the
+    wheel's copies are loaded first -- the runtime torch itself will use, and the one every test and bench run of this package
+    has run on (they import torch first) -- whatever the import order."""
+    if os.environ.get("DR_SYSTEM_ROCM"):
+        return None
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return None
+    if spec is None or not spec.origin:
+        return None
+    d = os.path.join(os.path.dirname(spec.origin), "lib")
+    return d if os.path.exists(os.path.join(d, "libamdhip64.so")) else None
+
+
 def load_library(path=None):
     """dlopen the HIP library; raises if it has not been built (no fallback)."""
     global _lib
@@ -61,7 +84,14 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise DaisyRiotError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(make -C daisyriot_amd/csrc). There is no CPU fallback." % path)
+    tdir = _torch_rocm_dir()
+    if tdir and "torch" not in sys.modules:
+        C.CDLL(os.path.join(tdir, "libamdhip64.so"), mode=C.RTLD_GLOBAL)     # SONAME libamdhip64.so.7: what our NEEDED entry asks for
     L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    L.dr_comm_set_library.argtypes = [C.c_char_p]
+    L.dr_comm_library_info.argtypes = [C.c_char_p, C.c_size_t]
+    if tdir and not os.environ.get("DR_RCCL_LIB") and os.path.exists(os.path.join(tdir, "librccl.so")):
+        L.dr_comm_set_library(os.path.join(tdir, "librccl.so").encode())   # bound (dlopen) at the first dr_comm_* call only
     vp, i = C.c_void_p, C.c_int
     L.dr_last_error.restype = C.c_char_p
     L.dr_context_create.argtypes = [i, C.POINTER(vp)]
@@ -168,6 +198,16 @@ def vis_exchange_fits(N, world, keep_visibility, device_bytes):
     """does a world-way assembly take the ray-count exchange path on cards of device_bytes?  (no rank argument: every
     rank must decide alike) -- pure host arithmetic of the library"""
     return bool(load_library().dr_vis_exchange_fits(int(N), int(world), int(bool(keep_visibility)), int(device_bytes)))
+
+
+def comm_library_info():
+    """(file the RCCL symbols are bound from, [every RCCL file mapped into the process])"""
+    L = load_library()
+    buf = C.create_string_buffer(4096)
+    if L.dr_comm_library_info(buf, len(buf)):
+        raise DaisyRiotError("dr_comm_library_info: %s" % L.dr_last_error().decode())
+    bound, mapped = buf.value.decode().split(";mapped=")
+    return bound[len("bound="):], [m for m in mapped.split(",") if m]
 
 
 def comm_unique_id():

@@ -61,6 +61,8 @@ struct dr_context {
     TriRec *d_tri = nullptr, *d_tri_sorted = nullptr;
     BvhNode* d_bvh = nullptr;
     BvhNode* d_bvh_lh = nullptr;      // the nodes as lower / upper corners (sign-specialised node test)
+    BvhPair *d_pairs = nullptr, *d_pairs_lh = nullptr;   // the tree in sibling-pair form (BvhPair), both box forms
+    int tree_depth = 0;               // depth of the written tree (the pair walk's stack holds one item per level)
     BvhNode* d_path_rec = nullptr;    // [N][PATH_RECS] path records of the patches (PathHdr, dr_internal.h)
     PathHdr* d_path_hdr = nullptr;
     int n_nodes = 0;
@@ -94,6 +96,7 @@ struct dr_context {
     unsigned* d_tickets = nullptr;    // in-launch reductions of the pass (SweepParams::tickets)
     double* d_blk_sums = nullptr;
     int* d_ctl = nullptr;             // [0] passes done, [1] a pass found the residual converged (SweepParams::ctl)
+    int fault_assemble_rank = -1;     // tests: the rank whose first assembly launch "fails" (DR_FAULT_ASSEMBLE_RANK, read at creation)
     int check_every = 8;              // dr_solver_converge looks at d_ctl once per this many queued passes
     bool tails_valid = false;         // the current residual's chunk tails hold its per-bin sums
     // optional zero-block skipping of the light pass (dr_solver_skip_zero_blocks)
@@ -148,6 +151,7 @@ void free_scene(dr_context* c) {
     hipFree(c->d_patch); hipFree(c->d_tri); hipFree(c->d_tri_sorted); hipFree(c->d_bvh);
     hipFree(c->d_path_rec); hipFree(c->d_path_hdr); c->d_path_rec = nullptr; c->d_path_hdr = nullptr;
     hipFree(c->d_bvh_lh); c->d_bvh_lh = nullptr;
+    hipFree(c->d_pairs); hipFree(c->d_pairs_lh); c->d_pairs = c->d_pairs_lh = nullptr;
     c->d_vtx = c->d_nrm = nullptr; c->d_tv = c->d_tn = nullptr;
     c->d_patch = nullptr; c->d_tri = nullptr; c->d_tri_sorted = nullptr; c->d_bvh = nullptr; c->N = 0;
 }
@@ -299,6 +303,7 @@ int dr_context_create(int device_id, dr_context** out) {
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(DR_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
+    if (const char* fe = getenv("DR_FAULT_ASSEMBLE_RANK")) c->fault_assemble_rank = atoi(fe);
     e = hipMalloc(&c->d_counter, 16 * sizeof(unsigned long long));
     if (e != hipSuccess) { hipStreamDestroy(c->own_stream); delete c; return fail(DR_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
     *out = c;
@@ -408,6 +413,8 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     c->n_nodes = 2 * N - 1;
     HIPCHK(hipMalloc(&c->d_bvh, sizeof(BvhNode) * ((size_t)c->n_nodes + 2)));     // + the sentinel + one node the walk's prefetch may touch
     HIPCHK(hipMalloc(&c->d_bvh_lh, sizeof(BvhNode) * ((size_t)c->n_nodes + 2)));
+    HIPCHK(hipMalloc(&c->d_pairs, sizeof(BvhPair) * (size_t)std::max(N - 1, 1)));
+    HIPCHK(hipMalloc(&c->d_pairs_lh, sizeof(BvhPair) * (size_t)std::max(N - 1, 1)));
     // the per-patch path records (1 KiB per patch) are only built for the experimental walk that uses them (DR_PATHS=1)
     if (const char* e = getenv("DR_PATHS"); e && atoi(e) != 0) {
         HIPCHK(hipMalloc(&c->d_path_rec, sizeof(BvhNode) * (size_t)N * PATH_RECS));
@@ -422,7 +429,7 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     HIPCHK(ev.create());
     HIPCHK(hipEventRecord(ev.a, c->stream));
     hipError_t be = build_lbvh(c->stream, N, c->d_tri, lo, hi, node_pad, c->d_bvh, c->d_bvh_lh, c->d_tri_sorted, &c->n_nodes, c->d_path_rec, c->d_path_hdr,
-                               c->shared_sah);
+                               c->shared_sah, c->d_pairs, c->d_pairs_lh, &c->tree_depth);
     if (be != hipSuccess) return fail(DR_ERR_DEVICE, "LBVH build failed: %s", hipGetErrorString(be));
     HIPCHK(hipEventRecord(ev.b, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -494,6 +501,9 @@ static int assemble_launch(dr_context* c, int K, float eps, int rule, int trace,
         p.uv = c->d_uv; p.pairs_traced = c->d_counter;
         // DR_OCTANT=0: the general node test for every pair (A/B runs)
         { const char* e = getenv("DR_OCTANT"); p.bvh_lh = (e && !atoi(e)) ? nullptr : c->d_bvh_lh; }
+        // the walk: over the sibling-pair records unless the tree is deeper than its stack (or DR_WALK=threaded)
+        { const char* e = getenv("DR_WALK"); const bool pw = !(e && !strcmp(e, "threaded")) && c->tree_depth <= PAIR_STACK - 2;
+          p.pairs = pw ? c->d_pairs : nullptr; p.pairs_lh = (pw && p.bvh_lh) ? c->d_pairs_lh : nullptr; }
         // DR_PATHS=1: the pairs' walks run over the two patches' path records instead of starting at the root (exact, measured
         // slower: profiles/r02/assembly_notes.md)
         { const char* e = getenv("DR_PATHS"); const bool on = (e ? atoi(e) != 0 : false) && c->d_path_rec && c->d_path_hdr;
@@ -568,11 +578,15 @@ int dr_vis_exchange_fits(int N, int world, int keep_visibility, size_t device_by
 }
 
 // every rank's go (1) / no-go (0) before a collective: all ranks return the minimum
+// The buffer exists since dr_comm_init (no allocation here that could fail on one rank only); a local HIP failure on the way
+// in does not skip the all-gather -- the peers are in it -- it is reported afterwards, and the verdict is then "no".
 static int comm_agree(dr_context* c, int ok, int* all_ok) {
-    if (!c->d_agree) HIPCHK(hipMalloc(&c->d_agree, sizeof(int) * (size_t)std::max(c->world, 1)));
-    HIPCHK(hipMemcpyAsync(c->d_agree + c->rank, &ok, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));      // `ok` is a stack variable
+    *all_ok = 0;
+    if (!c->d_agree) return fail(DR_ERR_STATE, "no agreement buffer: dr_comm_init has not been called");
+    hipError_t he = hipMemcpyAsync(c->d_agree + c->rank, &ok, sizeof(int), hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);      // `ok` is a stack variable
     std::string err = comm_allgather_i32_inplace(c->comm, c->d_agree, c->stream);
+    if (he != hipSuccess) return fail(DR_ERR_DEVICE, "go / no-go upload failed: %s", hipGetErrorString(he));
     if (!err.empty()) return fail(DR_ERR_COMM, "%s", err.c_str());
     std::vector<int> h((size_t)c->world);
     HIPCHK(hipMemcpyAsync(h.data(), c->d_agree, sizeof(int) * h.size(), hipMemcpyDeviceToHost, c->stream));
@@ -605,10 +619,16 @@ int dr_formfactors_assemble(dr_context* c, const float* uv, int K, float eps, in
     if (rc) return rc;
     if (rc2) return rc2;
     if (!all_ok) return fail(DR_ERR_COMM, "another rank could not set up the assembly; nothing was traced");
-    rc = assemble_launch(c, K, eps, rule, 1, 1);
-    if (rc) return rc;
-    rc = assemble_complete(c, 1);
-    if (rc) return rc;
+    // the first launch, then a second go / no-go: a rank whose kernel failed to launch or faulted must not leave the others
+    // waiting in the all-to-all (it still takes part in the agreement -- a failed launch leaves the stream usable)
+    rc = (c->fault_assemble_rank == c->rank) ? fail(DR_ERR_DEVICE, "injected failure of the first assembly launch (DR_FAULT_ASSEMBLE_RANK)")
+                                              : assemble_launch(c, K, eps, rule, 1, 1);
+    if (rc == DR_OK) rc = assemble_complete(c, 1);
+    const std::string first_err = rc ? g_err : std::string();
+    rc2 = comm_agree(c, rc == DR_OK ? 1 : 0, &all_ok);
+    if (rc) return fail(rc, "%s", first_err.c_str());
+    if (rc2) return rc2;
+    if (!all_ok) { c->split_pending = false; return fail(DR_ERR_COMM, "another rank failed in the first assembly launch; the ray counts were not exchanged"); }
     std::string err = comm_alltoall_bytes(c->comm, c->d_vsend, c->d_vrecv, c->vx_block, c->stream);
     if (!err.empty()) return fail(DR_ERR_COMM, "%s", err.c_str());
     return assemble_impl(c, nullptr, c->split_K, c->split_eps, c->split_rule, 0, 1, 2);
@@ -678,11 +698,12 @@ int dr_formfactors_read_rows(dr_context* c, int row0, int nrows, float* out) {
 
 int dr_visibility_read_rows(dr_context* c, int row0, int nrows, uint8_t* out) {
     CTX(c);
-    if (!c->have_F || !c->d_vis) return fail(DR_ERR_STATE, "visibility counts were not kept (keep_visibility = 0)");
+    if (!c->have_F) return fail(DR_ERR_STATE, "form factors not assembled");
     if (!out) return fail(DR_ERR_INVALID, "out is null");
     int rc = check_rows(c, row0, nrows);
     if (rc) return rc;
-    if (nrows == 0) return DR_OK;
+    if (nrows == 0) return DR_OK;          // (a rank without rows keeps no counts)
+    if (!c->d_vis) return fail(DR_ERR_STATE, "visibility counts were not kept (keep_visibility = 0)");
     HIPCHK(hipMemcpyAsync(out, c->d_vis + (size_t)(row0 - c->row0) * c->N, (size_t)nrows * c->N, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return DR_OK;
@@ -915,6 +936,19 @@ int dr_display_vertex_colors(dr_context* c, const float* rgb_all, const int32_t*
     return DR_OK;
 }
 
+int dr_comm_set_library(const char* path) {
+    std::string e = comm_set_library(path);
+    if (!e.empty()) return fail(DR_ERR_STATE, "%s", e.c_str());
+    return DR_OK;
+}
+
+int dr_comm_library_info(char* out, size_t n) {
+    if (!out || n == 0) return fail(DR_ERR_INVALID, "out is null");
+    const std::string s = comm_library_info();
+    snprintf(out, n, "%s", s.c_str());
+    return DR_OK;
+}
+
 int dr_comm_unique_id(void* out128) {
     if (!out128) return fail(DR_ERR_INVALID, "out128 is null");
     std::string e = comm_unique_id(out128);
@@ -927,6 +961,7 @@ int dr_comm_init(dr_context* c, const void* id128, int rank, int world) {
     if (!id128) return fail(DR_ERR_INVALID, "id128 is null");
     if (rank != c->rank || world != c->world) return fail(DR_ERR_INVALID, "comm %d/%d does not match shard %d/%d", rank, world, c->rank, c->world);
     comm_destroy(c->comm);
+    if (!c->d_agree) HIPCHK(hipMalloc(&c->d_agree, sizeof(int) * (size_t)std::max(c->world, 1)));     // comm_agree's buffer
     std::string e = comm_init(c->comm, id128, rank, world);
     if (!e.empty()) return fail(DR_ERR_COMM, "%s", e.c_str());
     return DR_OK;

@@ -4,6 +4,7 @@
 #include "dr_comm.h"
 
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
 #include <cstdlib>
 #include <cstring>
@@ -35,24 +36,37 @@ void bind(Api& a, F& f, const char* name) {
     if (!f && a.err.empty()) a.err = std::string("RCCL symbol missing: ") + name;
 }
 
+// the library to bind, set before the first use (comm_set_library); empty: DR_RCCL_LIB, else a copy already in the process,
+// else the system's
+std::string g_forced_lib;
+std::mutex g_lib_mu;
+bool g_bound = false;
+
+// Everything is opened RTLD_LOCAL.  A host process may map a SECOND RCCL later (importing torch loads the copy bundled with
+// it: its NEEDED entry is the file name `librccl.so`, which the loader does not match with an already loaded SONAME
+// `librccl.so.1`); with RTLD_GLOBAL the first copy's symbols would interpose the second's and the two runtimes tear each other
+// down at exit ("double free or corruption", round 2's gpurun_out/r2_crash.log).  Opened locally the copies stay apart.
 Api& api() {
     static Api a;
     static std::once_flag once;
     std::call_once(once, [] {
-        // DR_RCCL_LIB: bind this library instead (tests: a loop-back stand-in that lets several ranks share one GPU)
-        if (const char* forced = getenv("DR_RCCL_LIB")) {
-            a.h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
-            if (!a.h) { a.err = std::string("DR_RCCL_LIB: ") + dlerror(); return; }
+        { std::lock_guard<std::mutex> lk(g_lib_mu); g_bound = true; }
+        // an explicit choice (dr_comm_set_library), or DR_RCCL_LIB (tests: a loop-back stand-in that lets several ranks share
+        // one GPU)
+        const char* forced = !g_forced_lib.empty() ? g_forced_lib.c_str() : getenv("DR_RCCL_LIB");
+        if (forced && *forced) {
+            a.h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!a.h) { a.err = std::string("RCCL library ") + forced + ": " + dlerror(); return; }
         }
         // prefer a copy already mapped into the process (same SONAME as torch's bundled one)
         const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
         if (!a.h) for (const char* n : names) {
-            a.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+            a.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
             if (a.h) break;
         }
         if (!a.h)
             for (const char* n : names) {
-                a.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+                a.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
                 if (a.h) break;
             }
         if (!a.h) { a.err = std::string("RCCL not found: ") + dlerror(); return; }
@@ -70,6 +84,12 @@ Api& api() {
         a.errstr = (decltype(a.errstr))dlsym(a.h, "ncclGetErrorString");
     });
     return a;
+}
+
+// every object mapped into the process whose file name says RCCL
+int collect_rccl(struct dl_phdr_info* info, size_t, void* out) {
+    if (info->dlpi_name && std::strstr(info->dlpi_name, "rccl")) static_cast<std::vector<std::string>*>(out)->push_back(info->dlpi_name);
+    return 0;
 }
 
 std::string nccl_err(const char* what, ncclResult_t rc) {
@@ -91,6 +111,26 @@ std::string read_back(Comm& c) {
 }
 
 }  // namespace
+
+std::string comm_set_library(const char* path) {
+    std::lock_guard<std::mutex> lk(g_lib_mu);
+    if (g_bound) return "the RCCL library is already bound (dr_comm_set_library must come before the first dr_comm_* / dr_group_create call)";
+    g_forced_lib = path ? path : "";
+    return "";
+}
+
+std::string comm_library_info() {
+    Api& a = api();
+    std::string out = "bound=";
+    Dl_info di;
+    if (a.get_id && dladdr(reinterpret_cast<void*>(a.get_id), &di) && di.dli_fname) out += di.dli_fname;
+    else out += a.err.empty() ? "?" : "(none: " + a.err + ")";
+    std::vector<std::string> all;
+    dl_iterate_phdr(collect_rccl, &all);
+    out += ";mapped=";
+    for (size_t i = 0; i < all.size(); i++) out += (i ? "," : "") + all[i];
+    return out;
+}
 
 std::string comm_unique_id(void* out128) {
     Api& a = api();

@@ -1,4 +1,4 @@
-// dr_comm.h -- RCCL bound at run time (dlopen), so the library has no link-time RCCL
+// dr_comm.h -- RCCL bound at run time (dlopen, RTLD_LOCAL), so the library has no link-time RCCL
 // dependency and shares the copy a host process (e.g. torch) has already loaded.  Types, enum values and
 // prototypes come from <rccl/rccl.h>; only the symbol lookup is deferred.
 #pragma once
@@ -14,6 +14,10 @@ struct Comm {
     int rank = 0, world = 1;  // what the communicator itself reports (ncclCommUserRank / ncclCommCount), read back at init
 };
 
+// which RCCL to bind: a path, before the first use (empty / null: the default search); error text if already bound
+std::string comm_set_library(const char* path);
+// "bound=<file the bound symbols live in>;mapped=<every RCCL file mapped into the process, comma separated>"
+std::string comm_library_info();
 // fills out[128]; returns empty string on success, else the error text
 std::string comm_unique_id(void* out128);
 std::string comm_init(Comm& c, const void* id128, int rank, int world);

@@ -40,6 +40,15 @@ struct BvhNode {
 };                      // 32 B: one s_load_dwordx8
 constexpr int BVH_END = 0x7ffffff8;
 
+// The same tree in SIBLING-PAIR form: one 64-byte record per interior node holding the boxes of its TWO CHILDREN (c[0] left,
+// c[1] right; box fields as in BvhNode), so that one s_load_dwordx16 buys two node tests and a child that is rejected is never
+// fetched.  A child's `skip` field is its ITEM: >= 0 the byte offset of the child's own record (an interior child), < 0 a leaf:
+// 0x80000000 | leaf code (leaf code as BvhNode::tri).  Records lie in pre-order of the interior nodes, the root's first.  The
+// walk keeps the items still to do on a stack of at most PAIR_STACK entries (the lanes of one VGPR): trees deeper than that
+// are walked in the threaded form.
+struct BvhPair { BvhNode c[2]; };       // 64 B: one s_load_dwordx16
+constexpr int PAIR_STACK = 64;
+
 // Per-patch PATH RECORDS.  Every ray of a pair (lo, hi) starts on patch lo and ends on patch hi, so it is inside every
 // ancestor of the two patches' leaves: testing those nodes (a quarter of a walk from the root) tells nothing.  What a
 // walk does need are the SIBLINGS hanging off the two root-to-leaf paths -- together with the two leaves they cover the
@@ -75,6 +84,8 @@ struct TileParams {
     const TriRec* tri_sorted;   // Morton order, LEAF_MAX never-hit padding records at the end (leaf tests)
     const BvhNode* bvh;
     const BvhNode* bvh_lh;      // the same nodes with c[] = lower, h[] = upper corner (sign-specialised node test); null: not used
+    const BvhPair* pairs;       // sibling-pair form of the tree (BvhPair), centre / half-extent; null: the threaded form is walked
+    const BvhPair* pairs_lh;    // ... lower / upper corner
     const BvhNode* path_rec;    // [N][PATH_RECS] path records (see PathHdr); null: every walk starts at the root
     const PathHdr* path_hdr;    // [N]
     const float* uv;          // K x 2
@@ -166,7 +177,9 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float scen
                       BvhNode* nodes_lh /* the same in lower / upper corner form */,
                       TriRec* tri_sorted /* N + LEAF_MAX */, int* n_nodes_out,
                       BvhNode* path_rec /* N * PATH_RECS */, PathHdr* path_hdr /* N */,
-                      SahTopology* shared = nullptr /* N == this mesh's: use it; else fill it */);
+                      SahTopology* shared = nullptr /* N == this mesh's: use it; else fill it */,
+                      BvhPair* pairs = nullptr /* room for max(N - 1, 1): the sibling-pair form, centre / half-extent */,
+                      BvhPair* pairs_lh = nullptr /* lower / upper corner */, int* depth_out = nullptr /* depth of the written tree */);
 void sah_topology_from_boxes(int N, const float* boxes /* N x {lo[3], hi[3]} */, SahTopology& out);
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p);
 hipError_t launch_sweep(hipStream_t st, const SweepParams& p);

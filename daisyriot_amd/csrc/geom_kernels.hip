@@ -245,19 +245,28 @@ __global__ void k_emit(int N, const int* __restrict__ left, const int* __restric
                        const int* __restrict__ last, const int* __restrict__ parent,
                        const float* __restrict__ box, const int* __restrict__ esize, float node_pad,
                        const TriRec* __restrict__ tri_sorted, BvhNode* __restrict__ nodes, BvhNode* __restrict__ nodes_lh,
-                       int* __restrict__ pre /* 2N-1, preset to -1: pre-order index of every node that is written */) {
+                       int* __restrict__ pre /* 2N-1, preset to -1: pre-order index of every node that is written */,
+                       BvhPair* __restrict__ pairs, BvhPair* __restrict__ pairs_lh, int* __restrict__ depth_max) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= 2 * N - 1) return;
     const bool internal = id < N - 1;
     const int f = internal ? first[id] : id - (N - 1);
     const int cnt = internal ? last[id] - first[id] + 1 : 1;
     int idx = 0;
+    // the same walk to the root also gives the node's index among the written INTERIOR nodes in pre-order (a written subtree
+    // of es nodes is a full binary tree: (es - 1) / 2 of them are interior), its parent's, and its depth: the pair records
+    int iidx = 0, first_di = 0, depth = 0;
+    bool is_right = false;
     int cur = id;
     while (cur != 0 && N > 1) {
         int p = parent[cur];
         if (last[p] - first[p] + 1 <= LEAF_MAX) return;      // inside a collapsed subtree
         idx += 1;
-        if (left[p] != cur) idx += esize[left[p]];
+        int di = 1;
+        if (left[p] != cur) { idx += esize[left[p]]; di += (esize[left[p]] - 1) >> 1; }
+        if (cur == id) { first_di = di; is_right = left[p] != cur; }
+        iidx += di;
+        depth++;
         cur = p;
     }
     BvhNode nd;
@@ -289,6 +298,27 @@ __global__ void k_emit(int N, const int* __restrict__ left, const int* __restric
     }
     nodes_lh[idx] = lh;
     pre[id] = idx;
+    // The sibling-pair form of the same tree (BvhPair, dr_internal.h): this node's box and "item" go into its PARENT's record.
+    if (pairs != nullptr) {
+        const int item = (cnt <= LEAF_MAX) ? (int)(0x80000000u | (unsigned)nd.tri) : iidx * (int)sizeof(BvhPair);
+        if (depth > 0) {
+            BvhNode a = nd, b = lh;
+            a.skip = item; a.tri = 0; b.skip = item; b.tri = 0;
+            pairs[iidx - first_di].c[is_right ? 1 : 0] = a;
+            pairs_lh[iidx - first_di].c[is_right ? 1 : 0] = b;
+        } else if (cnt <= LEAF_MAX) {
+            // the root is a leaf (one or two triangles): one pseudo record -- all-space boxes, the leaf and a leaf of the
+            // never-hit padding records behind the last triangle
+            BvhNode a, b;
+            for (int x = 0; x < 3; x++) { a.c[x] = 0.0f; a.h[x] = INFINITY; b.c[x] = -INFINITY; b.h[x] = INFINITY; }
+            a.tri = 0; b.tri = 0;
+            a.skip = item; b.skip = item;
+            pairs[0].c[0] = a; pairs_lh[0].c[0] = b;
+            a.skip = b.skip = (int)(0x80000000u | (unsigned)(N * 8));
+            pairs[0].c[1] = a; pairs_lh[0].c[1] = b;
+        }
+        atomicMax(depth_max, depth);
+    }
 }
 
 // The path records of every patch (PathHdr, dr_internal.h): climb from the patch's leaf to the root, copying the sibling
@@ -474,7 +504,7 @@ void sah_topology_from_boxes(int N, const float* boxes, SahTopology& out) {
 
 hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[3], const float shi[3], float node_pad,
                       BvhNode* nodes, BvhNode* nodes_lh, TriRec* tri_sorted, int* n_nodes_out, BvhNode* path_rec, PathHdr* path_hdr,
-                      SahTopology* shared) {
+                      SahTopology* shared, BvhPair* pairs, BvhPair* pairs_lh, int* depth_out) {
     hipError_t e;
     unsigned long long *keys = nullptr, *keys2 = nullptr;
     int *vals = nullptr, *vals2 = nullptr, *ibuf = nullptr;
@@ -492,7 +522,7 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
     DR_TRY(hipMalloc(&vals, sizeof(int) * N));
     DR_TRY(hipMalloc(&vals2, sizeof(int) * N));
     // left,right,first,last,flags: N-1 each; parent, esize, pre: 2N-1 each; pos: N
-    DR_TRY(hipMalloc(&ibuf, sizeof(int) * (6 * (size_t)N + 3 * nn)));
+    DR_TRY(hipMalloc(&ibuf, sizeof(int) * (6 * (size_t)N + 3 * nn + 1)));
     DR_TRY(hipMalloc(&box, sizeof(float) * 6 * nn));
     {
         int* left = ibuf; int* right = ibuf + N; int* first = ibuf + 2 * (size_t)N;
@@ -500,6 +530,7 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
         int* esize = parent + nn;
         int* pre = esize + nn;
         int* pos = pre + nn;
+        int* depth_max = pos + N;
         const int nb = (N + 255) / 256;
         const char* km = getenv("DR_BVH_KEY");
         const int key_mode = km ? atoi(km) : 0;
@@ -546,8 +577,11 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
         hipLaunchKernelGGL(k_pad_tris, dim3(1), dim3(64), 0, st, N, tri_sorted);
         DR_TRY(hipGetLastError());
         DR_TRY(hipMemsetAsync(pre, 0xff, sizeof(int) * nn, st));
-        hipLaunchKernelGGL(k_emit, dim3((int)((nn + 255) / 256)), dim3(256), 0, st, N, left, first, last, parent, box, esize, node_pad, tri_sorted, nodes, nodes_lh, pre);
+        DR_TRY(hipMemsetAsync(depth_max, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_emit, dim3((int)((nn + 255) / 256)), dim3(256), 0, st, N, left, first, last, parent, box, esize, node_pad, tri_sorted, nodes, nodes_lh, pre,
+                           pairs, pairs_lh, depth_max);
         DR_TRY(hipGetLastError());
+        if (depth_out) DR_TRY(hipMemcpyAsync(depth_out, depth_max, sizeof(int), hipMemcpyDeviceToHost, st));
         if (path_rec && path_hdr) {
             hipLaunchKernelGGL(k_paths, dim3(nb), dim3(256), 0, st, N, pos, left, right, parent, pre, nodes, path_rec, path_hdr);
             DR_TRY(hipGetLastError());
@@ -723,6 +757,7 @@ __device__ __forceinline__ void integrand_pair(const float* ri, const float* rj,
 #define DR_B5 "s53"
 #define DR_B6 "s54"
 #define DR_B7 "s55"
+#define DR_AB_ALL "s[48:63]"
 #define DR_WALK_CLOBBERS "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63"
 #else
 #define DR_A_ALL "s[88:95]"
@@ -743,13 +778,18 @@ __device__ __forceinline__ void integrand_pair(const float* ri, const float* rj,
 #define DR_B5 "s85"
 #define DR_B6 "s86"
 #define DR_B7 "s87"
+#define DR_AB_ALL "s[80:95]"
 #define DR_WALK_CLOBBERS "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95"
 #endif
 
 // The triangles of one leaf against the wave's rays: the lanes (of alive_m) for which one of them precedes the destination
 // `hi` -- nearer, or at equal t with a lower id.  leaf = first*8 + (count-1) [+4: both triangles share one gate box].
 // The leaf's LEAF_MAX records (64 B each: triangle, id, gate box) are fetched together -- no dependent loads inside the
-// leaf; a triangle's Moller-Trumbore test only runs when some live lane passes its gate.
+// leaf.  A hit is gate AND Moller-Trumbore (oracle.c); the conjunction is evaluated cheapest-rejection first: the leaf's NODE
+// box was touched, so the triangles' gates nearly always pass (10.5 triangle tests start per pair where 11 are possible),
+// whereas 46 % of the tests end at u and 80 % of the rest at v (profiles/r02/assembly_notes.md) -- the gate (24 vector
+// instructions) is therefore only formed for the one test in nine that survives both exclusion tests.  Same values in the
+// same order for every lane that can hit.
 __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __restrict__ tri_sorted, int leaf, f3 org, f3 dn, f3 inv,
                                                                 float tmax, int hi, unsigned long long alive_m) {
     const int first = leaf >> 3, cnt = (leaf & 3) + 1;
@@ -758,16 +798,12 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
     v4f q[4 * LEAF_MAX];
 #pragma unroll
     for (int c = 0; c < 4 * LEAF_MAX; c++) q[c] = tp[c];
-    unsigned long long blocked_m = 0ull, gm_prev = 0ull;
+    unsigned long long blocked_m = 0ull, gm_first = 0ull;
+    bool have_first = false;
 #pragma unroll
     for (int c = 0; c < LEAF_MAX; c++) {
         const v4f A = q[4 * c], B = q[4 * c + 1], C3 = q[4 * c + 2], D = q[4 * c + 3];
-        const float blo[3] = { C3[2], C3[3], D[0] }, bhi[3] = { D[1], D[2], D[3] };
-        unsigned long long gm;
-        if (c == 1 && same_gate) gm = gm_prev;     // bit-identical box: the same mask
-        else gm = box_hit_mask(blo, bhi, org, inv, tmax) & alive_m;
-        gm_prev = gm;
-        if (gm == 0ull || c >= cnt) continue;      // (slots past the leaf's count belong to the next leaf)
+        if (c >= cnt) continue;                    // (slots past the leaf's count belong to the next leaf)
         const int tk = __builtin_amdgcn_readfirstlane(__float_as_int(C3[1]));
         if (tk == hi) continue;                    // the destination: its t is tmax bit for bit, it never precedes itself
         const f3 ta = f3{ A[0], A[1], A[2] };
@@ -777,7 +813,8 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
         // NUMERATORS: u = au * fl(1/det) lies outside [0, 1] for sure when |au| > |det| (1 + 2^-21) (then |u| > 1 after both
         // roundings, or is infinite) or when au and det differ in sign and |au| > 2^-100 |det| (then u < 0 strictly: the product
         // cannot underflow to -0, and au = 0 -- whose u = -0 passes u >= 0 -- is never excluded); the same for v, which a hit also needs in [0, 1] (v >= 0, and u + v <= 1 with u >= 0).  Only when
-        // some gated lane survives both is 1/det formed (11 instructions) and u, v, u + v, t tested as the definition says.
+        // some live lane survives both is the gate formed, and only when some lane passes that too 1/det (11 instructions) and
+        // u, v, u + v, t tested as the definition says.
         const f3 pv = cross3(dn, te2);
         const float det = dot3(te1, pv);
         const f3 tv = org - ta;
@@ -785,7 +822,7 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
         const float ad = fabsf(det), m_hi = ad * 1.0000005f, m_lo = ad * 7.888609e-31f;       // (1 + 2^-21, 2^-100)
         const unsigned long long out_u = __builtin_amdgcn_fcmpf(fabsf(au), m_hi, 2) |
                                          (__builtin_amdgcn_ballot_w64((__float_as_int(au) ^ __float_as_int(det)) < 0) & __builtin_amdgcn_fcmpf(fabsf(au), m_lo, 2));
-        unsigned long long cm = gm & ~out_u;
+        unsigned long long cm = alive_m & ~out_u;
         if (cm == 0ull) continue;
         const f3 qv = cross3(tv, te1);
         const float av = dot3(dn, qv);
@@ -793,9 +830,19 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
                                          (__builtin_amdgcn_ballot_w64((__float_as_int(av) ^ __float_as_int(det)) < 0) & __builtin_amdgcn_fcmpf(fabsf(av), m_lo, 2));
         cm &= ~out_v;
         if (cm == 0ull) continue;
+        // the gate (the second triangle of a quad has the first one's box bit for bit: the same mask)
+        unsigned long long gm;
+        if (c == 1 && same_gate && have_first) gm = gm_first;
+        else {
+            const float blo[3] = { C3[2], C3[3], D[0] }, bhi[3] = { D[1], D[2], D[3] };
+            gm = box_hit_mask(blo, bhi, org, inv, tmax);
+            if (c == 0) { gm_first = gm; have_first = true; }
+        }
+        cm &= gm;
+        if (cm == 0ull) continue;
         const float idet = 1.0f / det;
         const float u = au * idet, v = av * idet;
-        const unsigned long long vm = gm & __builtin_amdgcn_fcmpf(u, 0.0f, 3) & __builtin_amdgcn_fcmpf(v, 0.0f, 3) & __builtin_amdgcn_fcmpf(u + v, 1.0f, 5);
+        const unsigned long long vm = cm & __builtin_amdgcn_fcmpf(u, 0.0f, 3) & __builtin_amdgcn_fcmpf(v, 0.0f, 3) & __builtin_amdgcn_fcmpf(u + v, 1.0f, 5);
         if (vm == 0ull) continue;
         const float tt = dot3(te2, qv) * idet;
         const unsigned long long hm = vm & __builtin_amdgcn_fcmpf(tt, 0.0f, 2);
@@ -1083,7 +1130,147 @@ __device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restri
     return alive_m;
 }
 
-// The walk of ONE PAIR over its path records (PathHdr, dr_internal.h) -- the shipped walk.  A state machine with one copy
+// ---------------------------------------------------------------------------------------
+// The walk over the SIBLING-PAIR form of the tree (BvhPair, dr_internal.h) -- the shipped walk.
+//
+// The threaded walk above fetches every node it tests, one dependent 32-byte scalar load per node, and fetches a rejected
+// node only to learn where to go next (profiles/r02/pmc_asm_64k.txt: 148 scalar loads per pair, 44 % of them L2 round trips,
+// a wave 46 % of its time in s_waitcnt).  Here a record holds the boxes of BOTH children of an interior node: one
+// s_load_dwordx16 (one 64-byte line) lands in the same sixteen SGPRs the threaded walk uses as its two node sets, the two node
+// tests run back to back with nothing to wait for in between, a rejected child costs no fetch at all, and the items still to
+// do -- the second of two accepted children -- wait on a stack kept in the LANES OF ONE VGPR: v_writelane_b32 / v_readlane_b32
+// with the stack pointer in M0 (both ignore EXEC; no memory, no latency).  Half the fetches per pair for the same node tests.
+// An item is a record's byte offset (>= 0) or a leaf (< 0: 0x80000000 | leaf code); a leaf item ends the hand-written stretch
+// (leaf_blocked_mask runs as compiled code), the walk resumes by popping.  Same node tests as the threaded walk (DR_NODE_TEST_SX
+// per octant, DR_NODE_TEST_X for mixed signs), same grown boxes: equally conservative; what is hit is decided per triangle.
+// Stack depth: at most one pending item per level of the tree; the host only selects this walk for trees of depth <= PAIR_STACK - 2.
+// ---------------------------------------------------------------------------------------
+#define DR_PWALK_VARIANT(V, BVH, TESTL, TESTR)                                                                          \
+                V "0:\n\t"                                                                                              \
+                "s_cmp_eq_u32 m0, 0\n\t"                                                                                \
+                "s_cbranch_scc1 98f\n\t"                                                                                \
+                "s_add_u32 m0, m0, -1\n\t"                                                                              \
+                "s_nop 0\n\t"                                                                                           \
+                "v_readlane_b32 %[off], %[stk], m0\n"                                                                   \
+                V "1:\n\t"                                                                                              \
+                "s_cmp_lt_i32 %[off], 0\n\t"                                                                            \
+                "s_cbranch_scc1 99f\n\t"                                                                                \
+                "s_load_dwordx16 " DR_AB_ALL ", " BVH ", %[off] offset:0x0\n\t"                                         \
+                "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+                TESTL                                                                                                   \
+                "s_cbranch_vccz " V "4f\n\t"                                                                            \
+                TESTR                                                                                                   \
+                "s_cbranch_vccz " V "3f\n\t"                                                                            \
+                "v_writelane_b32 %[stk], " DR_A6 ", m0\n\t"                                                             \
+                "s_add_u32 m0, m0, 1\n"                                                                                 \
+                V "3:\n\t"                                                                                              \
+                "s_mov_b32 %[off], " DR_B6 "\n\t"                                                                       \
+                "s_branch " V "1b\n"                                                                                    \
+                V "4:\n\t"                                                                                              \
+                TESTR                                                                                                   \
+                "s_cbranch_vccz " V "0b\n\t"                                                                            \
+                "s_mov_b32 %[off], " DR_A6 "\n\t"                                                                       \
+                "s_branch " V "1b\n"
+// the left child is the record's first half = register set B, the right child set A
+#define DR_PWALK_OCTANT(V, SX, SY, SZ)                                                                                  \
+        DR_PWALK_VARIANT(V, "%[bvhlh]",                                                                                 \
+                DR_NODE_TEST_SX(DR_SEL(SX, DR_B0, DR_B3), DR_SEL(SY, DR_B1, DR_B4), DR_SEL(SZ, DR_B2, DR_B5),           \
+                               DR_SEL(SX, DR_B3, DR_B0), DR_SEL(SY, DR_B4, DR_B1), DR_SEL(SZ, DR_B5, DR_B2)),           \
+                DR_NODE_TEST_SX(DR_SEL(SX, DR_A0, DR_A3), DR_SEL(SY, DR_A1, DR_A4), DR_SEL(SZ, DR_A2, DR_A5),           \
+                               DR_SEL(SX, DR_A3, DR_A0), DR_SEL(SY, DR_A4, DR_A1), DR_SEL(SZ, DR_A5, DR_A2)))
+#define DR_PWALK_ASM                                                                                                    \
+            asm volatile(                                                                                               \
+                "s_mov_b64 %[sexec], exec\n\t"                                                                          \
+                "s_mov_b64 exec, %[alive]\n\t"                                                                          \
+                "s_mov_b32 m0, %[sp]\n\t"                                                                               \
+                "s_cmp_gt_u32 %[oct], 7\n\t"                                                                            \
+                "s_cbranch_scc1 80f\n\t"                                                                                \
+                "s_bitcmp1_b32 %[oct], 2\n\t"                                                                           \
+                "s_cbranch_scc1 94f\n\t"                                                                                \
+                "s_bitcmp1_b32 %[oct], 1\n\t"                                                                           \
+                "s_cbranch_scc1 92f\n\t"                                                                                \
+                "s_bitcmp1_b32 %[oct], 0\n\t"                                                                           \
+                "s_cbranch_scc1 10f\n\t"                                                                                \
+                "s_branch 00f\n"                                                                                        \
+                "92:\n\t"                                                                                               \
+                "s_bitcmp1_b32 %[oct], 0\n\t"                                                                           \
+                "s_cbranch_scc1 30f\n\t"                                                                                \
+                "s_branch 20f\n"                                                                                        \
+                "94:\n\t"                                                                                               \
+                "s_bitcmp1_b32 %[oct], 1\n\t"                                                                           \
+                "s_cbranch_scc1 96f\n\t"                                                                                \
+                "s_bitcmp1_b32 %[oct], 0\n\t"                                                                           \
+                "s_cbranch_scc1 50f\n\t"                                                                                \
+                "s_branch 40f\n"                                                                                        \
+                "96:\n\t"                                                                                               \
+                "s_bitcmp1_b32 %[oct], 0\n\t"                                                                           \
+                "s_cbranch_scc1 70f\n\t"                                                                                \
+                "s_branch 60f\n"                                                                                        \
+                DR_PWALK_OCTANT("0", 0, 0, 0)                                                                           \
+                DR_PWALK_OCTANT("1", 1, 0, 0)                                                                           \
+                DR_PWALK_OCTANT("2", 0, 1, 0)                                                                           \
+                DR_PWALK_OCTANT("3", 1, 1, 0)                                                                           \
+                DR_PWALK_OCTANT("4", 0, 0, 1)                                                                           \
+                DR_PWALK_OCTANT("5", 1, 0, 1)                                                                           \
+                DR_PWALK_OCTANT("6", 0, 1, 1)                                                                           \
+                DR_PWALK_OCTANT("7", 1, 1, 1)                                                                           \
+                DR_PWALK_VARIANT("8", "%[bvh]", DR_NODE_TEST_X(DR_B0, DR_B1, DR_B2, DR_B3, DR_B4, DR_B5),               \
+                                 DR_NODE_TEST_X(DR_A0, DR_A1, DR_A2, DR_A3, DR_A4, DR_A5))                              \
+                "98:\n\t"                                                                                               \
+                "s_mov_b32 %[off], 0x7ffffff8\n"                                                                        \
+                "99:\n\t"                                                                                               \
+                "s_mov_b32 %[sp], m0\n\t"                                                                               \
+                "s_mov_b64 exec, %[sexec]"                                                                              \
+                : [off] "=&s"(item), [sp] "+s"(sp), [stk] "+v"(stk), [sexec] "=&s"(sexec), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),   \
+                  [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5)                                                        \
+                : [bvh] "s"(pairs), [bvhlh] "s"(pairs_lh), [oct] "s"(octant), [alive] "s"(alive_m), [kx] "v"(kk.x), [ky] "v"(kk.y),   \
+                  [kz] "v"(kk.z), [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z)                                        \
+                : DR_WALK_CLOBBERS, "vcc", "scc", "m0")
+
+template <bool STATS>
+__device__ __forceinline__ unsigned long long walk_pairs(const BvhPair* __restrict__ pairs, const BvhPair* __restrict__ pairs_lh,
+                                                         const TriRec* __restrict__ tri_sorted, f3 org, f3 dn, f3 inv, f3 iv, f3 kk,
+                                                         float tmax, int hi, unsigned long long alive_m, int octant, int& n_visit, int& n_leaf) {
+    int stk = 0;            // lane 0 = the root's record (offset 0)
+    unsigned sp = 1u;
+    for (;;) {
+        int item;
+        if (STATS) {
+            // counted variant of the same walk (debug builds only)
+            item = BVH_END;
+            while (sp != 0u) {
+                sp--;
+                int it = __builtin_amdgcn_readlane(stk, (int)sp);
+                while (it >= 0) {
+                    const char* rp = reinterpret_cast<const char*>(pairs) + (unsigned)it;
+                    const v8f L = *reinterpret_cast<const v8f*>(rp), R = *reinterpret_cast<const v8f*>(rp + 32);
+                    const float lc[3] = { L[0], L[1], L[2] }, lh[3] = { L[3], L[4], L[5] }, rc[3] = { R[0], R[1], R[2] }, rh[3] = { R[3], R[4], R[5] };
+                    const int li = __builtin_amdgcn_readfirstlane(__float_as_int(L[6])), ri = __builtin_amdgcn_readfirstlane(__float_as_int(R[6]));
+                    n_visit += 2;
+                    const bool hl = (node_hit_mask(lc, lh, iv, kk, 1.0f) & alive_m) != 0ull, hr = (node_hit_mask(rc, rh, iv, kk, 1.0f) & alive_m) != 0ull;
+                    if (hl && hr) { stk = ((int)(threadIdx.x & 63u) == (int)sp) ? ri : stk; sp++; it = li; }
+                    else if (hl) it = li;
+                    else if (hr) it = ri;
+                    else { it = 0; break; }
+                }
+                if (it < 0) { item = it; break; }
+            }
+        } else {
+            float t0, t1, t2, t3, t4, t5;
+            unsigned long long sexec;
+            DR_PWALK_ASM;
+        }
+        if (item == BVH_END) break;
+        if (STATS) n_leaf++;
+        const unsigned long long blocked_m = leaf_blocked_mask(tri_sorted, item & 0x7fffffff, org, dn, inv, tmax, hi, alive_m);
+        alive_m &= ~blocked_m;
+        if (alive_m == 0ull) break;
+    }
+    return alive_m;
+}
+#undef DR_PWALK_ASM
+
+// The walk of ONE PAIR over its path records (PathHdr, dr_internal.h).  A state machine with one copy
 // of the hand-written node walk, one of the record stream and one of the leaf test:
 //   segments 0..2   path records, streamed (DR_STREAM_ASM: the next record is already loading while one is tested, their
 //                   addresses do not depend on any test): lo's records above the depth where the two paths part
@@ -1365,10 +1552,11 @@ __device__ __forceinline__ int build_shaft_list(const BvhNode* __restrict__ bvh,
 // debug-only instantiation.
 // amdgpu_num_sgpr(82) -> 80 SGPRs in the code object: the most with which a CU admits 8 blocks of 256 threads (the rest is
 // parked in VGPR lanes outside the pair loop); with 64 VGPRs and 19.7 KB of LDS that is 8 waves per SIMD, the hardware's maximum
-// WALK: 0 = every pair's walk starts at the root (shipped); 1 = over the tile pair's shaft list (build_shaft_list); 2 = over the
-// two patches' path records (walk_pair).  1 and 2 are exact and measured slower: profiles/r02/assembly_notes.md.
+// WALK: 3 = the walk over the sibling-pair records (walk_pairs; shipped); 0 = the threaded tree from the root (round 2's; trees
+// deeper than the pair walk's stack); 1 = over the tile pair's shaft list (build_shaft_list); 2 = over the two patches' path
+// records (walk_pair).  1 and 2 are exact and measured slower: profiles/r02/assembly_notes.md.
 template <int NT, bool STATS, int WALK>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82))) void k_ff_tiles(TileParams P) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82), amdgpu_waves_per_eu(8, 8))) void k_ff_tiles(TileParams P) {
     constexpr bool SHAFT = (WALK == 1), PATHS = (WALK == 2);
     const int t = blockIdx.x;
     const int o = P.tile0 + blockIdx.y;
@@ -1580,11 +1768,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82))) void k_ff_
                         from_root = (__builtin_amdgcn_ballot_w64(alive && !inb) != 0ull);
                         if (STATS && from_root && lane == 0 && P.dbg_lo < 0) atomicAdd(P.pairs_traced + 10, 1ull);
                     }
-                    if (WALK == 0) {
+                    if (WALK == 0 || WALK == 3) {
                         // the whole tree, sentinel-terminated: no end-of-range compares in the walk
                         // do all live rays point into one octant?  (they run from one patch to one patch: nearly always)
                         int octant = 8;
-                        if (P.bvh_lh != nullptr) {
+                        if ((WALK == 3 ? (const void*)P.pairs_lh : (const void*)P.bvh_lh) != nullptr) {
                             const unsigned long long nx = alive_m & __builtin_amdgcn_fcmpf(dn.x, 0.0f, 4), ny = alive_m & __builtin_amdgcn_fcmpf(dn.y, 0.0f, 4),
                                                      nz = alive_m & __builtin_amdgcn_fcmpf(dn.z, 0.0f, 4);
                             if ((nx == 0ull || nx == alive_m) && (ny == 0ull || ny == alive_m) && (nz == 0ull || nz == alive_m))
@@ -1592,8 +1780,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82))) void k_ff_
                         }
                         octant = __builtin_amdgcn_readfirstlane(octant);
                         if (STATS && octant == 8 && lane == 0 && P.dbg_lo < 0) atomicAdd(P.pairs_traced + 13, 1ull);
-                        alive_m = walk_range<STATS, false>(P.bvh, P.tri_sorted, root_off, end_all, org, dn, inv, iv, kk, tmax, tmax_w, hi, alive_m, n_visit, n_leaf,
-                                                           P.bvh_lh, octant);
+                        if (WALK == 3)
+                            alive_m = walk_pairs<STATS>(P.pairs, P.pairs_lh, P.tri_sorted, org, dn, inv, iv, kk, tmax, hi, alive_m, octant, n_visit, n_leaf);
+                        else
+                            alive_m = walk_range<STATS, false>(P.bvh, P.tri_sorted, root_off, end_all, org, dn, inv, iv, kk, tmax, tmax_w, hi, alive_m, n_visit, n_leaf,
+                                                               P.bvh_lh, octant);
                     }
                     if (PATHS) {
                         alive_m = walk_pair<STATS>(P.bvh, P.tri_sorted, rec_lo, rec_hi, ell, pDl, pDh, leaf_lo, leaf_hi, no_paths, end_all,
@@ -1679,15 +1870,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82))) void k_ff_
 
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p) {
     dim3 grid(p.nT, p.nOwnedTiles);
-    const int walk = p.shaft ? 1 : (p.path_hdr ? 2 : 0);
+    const int walk = p.shaft ? 1 : (p.path_hdr ? 2 : (p.pairs ? 3 : 0));
     if (p.stats & 1) {
         if (walk == 1) hipLaunchKernelGGL((k_ff_tiles<256, true, 1>), grid, dim3(256), 0, st, p);
         else if (walk == 2) hipLaunchKernelGGL((k_ff_tiles<256, true, 2>), grid, dim3(256), 0, st, p);
+        else if (walk == 3) hipLaunchKernelGGL((k_ff_tiles<256, true, 3>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((k_ff_tiles<256, true, 0>), grid, dim3(256), 0, st, p);
         return hipGetLastError();
     }
     if (walk == 1) { hipLaunchKernelGGL((k_ff_tiles<256, false, 1>), grid, dim3(256), 0, st, p); return hipGetLastError(); }
     if (walk == 2) { hipLaunchKernelGGL((k_ff_tiles<256, false, 2>), grid, dim3(256), 0, st, p); return hipGetLastError(); }
+    if (walk == 3) { hipLaunchKernelGGL((k_ff_tiles<256, false, 3>), grid, dim3(256), 0, st, p); return hipGetLastError(); }
     // (512 and 1024 threads per workgroup -- more waves sharing a queue -- measured 5 % and 14 % slower at 64k patches)
     hipLaunchKernelGGL((k_ff_tiles<256, false, 0>), grid, dim3(256), 0, st, p);
     return hipGetLastError();

@@ -567,8 +567,26 @@ static hipError_t launch_sweep_mfma(hipStream_t st, const SweepParams& p) {
     return hipGetLastError();
 }
 
+// A rank WITHOUT rows (shard_rows leaves the last ranks empty when N < world * rows-per-rank, e.g. the reference's 6400-patch
+// scene on 8 GPUs) still takes part in a converge run: it must take the same decision from the gathered sums as the ranks that
+// sweep, latch it, count the real passes -- dr_solver_converge reads ctl on every rank, and a rank that stopped queueing passes
+// would leave its peers alone in the all-gather -- and leave a zero tail in its (all-zero) chunk.
+__global__ void k_sweep_norows(SweepParams P) {
+    if (P.conv_mode != 0 && (P.ctl[1] != 0 || residual_converged(P))) {
+        if (threadIdx.x == 0) P.ctl[1] = 1;
+        return;
+    }
+    if (!P.want_sums) return;
+    if ((int)threadIdx.x < P.S) reinterpret_cast<double*>(P.Rout + (size_t)P.rank * P.cstride + (size_t)P.S * P.rpr)[threadIdx.x] = 0.0;
+    if (threadIdx.x == 0) P.ctl[0] = P.ctl[0] + 1;
+}
+
 hipError_t launch_sweep(hipStream_t st, const SweepParams& p_in) {
-    if (p_in.nrows <= 0) return hipSuccess;
+    if (p_in.nrows <= 0) {
+        if (p_in.conv_mode == 0 && !p_in.want_sums) return hipSuccess;
+        hipLaunchKernelGGL(k_sweep_norows, dim3(1), dim3(64), 0, st, p_in);
+        return hipGetLastError();
+    }
     SweepParams p = p_in;
     // Start tile of a block = blockIdx.x * skew (mod tiles).  While the gathered residual fits a slice of L2
     // (4 MiB per XCD) a skew decorrelates the blocks' column positions, worth +0.5 % at N = 65 536; once it does

@@ -191,6 +191,13 @@ int dr_display_vertex_colors(dr_context* ctx, const float* rgb_all, const int32_
                              const int32_t* vtx_tri, int V, float* out /* V*3 */);
 
 /* ---- multi-GPU exchange (no reference counterpart: the reference is single-GPU) ---- */
+/* RCCL is bound at run time, privately (dlopen RTLD_LOCAL): a copy with the SONAME librccl.so.1 that the process has
+ * already mapped, else the system's.  dr_comm_set_library names the file to bind instead (before the first dr_comm_* /
+ * dr_group_create call; the environment variable DR_RCCL_LIB does the same): a host that will later load another copy --
+ * a Python process that imports torch, which brings its own -- passes that copy's path so that one runtime serves both
+ * (daisyriot_amd/api.py does).  dr_comm_library_info: "bound=<file>;mapped=<every RCCL file in the process>". */
+int dr_comm_set_library(const char* path);
+int dr_comm_library_info(char* out, size_t n);
 /* 128-byte RCCL unique id made on rank 0 and handed to every rank by the host. */
 int dr_comm_unique_id(void* out128);
 int dr_comm_init(dr_context* ctx, const void* id128, int rank, int world);

@@ -3,10 +3,6 @@ import sys
 
 import pytest
 
-# torch first: it brings its own copy of RCCL, which libdaisyriot_hip.so then shares (dlopen RTLD_NOLOAD).  A test that made the
-# library load /opt/rocm's copy before a later test imported torch would leave two RCCL runtimes in one process (they abort at exit).
-import torch  # noqa: F401,E402
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -124,16 +124,18 @@ def test_tile_kernel_register_budget():
         pytest.skip("library built without the resource report")
     text = open(path).read()
     blocks = re.split(r"Function Name: ", text)[1:]
-    tile = [b for b in blocks if b.startswith("_ZN2dr10k_ff_tilesILi256ELb0ELi0EEE")]
-    assert len(tile) == 1, "default tile kernel not found in the resource report"
-    def val(name):
-        return int(re.search(name + r": (\d+)", tile[0]).group(1))
-    assert 64 <= val("TotalSGPRs") <= 80
-    # (SGPRs parked in VGPR lanes outside the pair loop are fine; memory spills are not)
-    assert val("VGPRs Spill") == 0 and val(r"ScratchSize \[bytes/lane\]") == 0
-    assert val("VGPRs") <= 64                                   # 8 waves per SIMD by registers
-    assert val(r"LDS Size \[bytes/block\]") <= 20480            # 8 blocks per CU by LDS
-    assert val(r"Occupancy \[waves/SIMD\]") == 8
+    # walk 3 = over the sibling-pair records (shipped), walk 0 = the threaded tree (trees deeper than the pair walk's stack)
+    for walk in (3, 0):
+        tile = [b for b in blocks if b.startswith("_ZN2dr10k_ff_tilesILi256ELb0ELi%dEEE" % walk)]
+        assert len(tile) == 1, "tile kernel (walk %d) not found in the resource report" % walk
+        def val(name):
+            return int(re.search(name + r": (\d+)", tile[0]).group(1))
+        assert 64 <= val("TotalSGPRs") <= 80
+        # (SGPRs parked in VGPR lanes outside the pair loop are fine; memory spills are not)
+        assert val("VGPRs Spill") == 0 and val(r"ScratchSize \[bytes/lane\]") == 0
+        assert val("VGPRs") <= 64                                   # 8 waves per SIMD by registers
+        assert val(r"LDS Size \[bytes/block\]") <= 20480            # 8 blocks per CU by LDS
+        assert val(r"Occupancy \[waves/SIMD\]") == 8
     src = open(os.path.join(ROOT, "daisyriot_amd", "csrc", "geom_kernels.hip")).read()
     named = sorted(set(int(x) for x in re.findall(r'#define DR_[AB][0-7] "s(\d+)"', src.split("#else")[0])))
     assert named == list(range(48, 64))
@@ -144,7 +146,7 @@ def test_tile_kernel_register_budget():
 def test_tile_kernel_walk_has_no_spill_reloads_around_it():
     """The register allocator's SGPR spill reloads (v_readlane) must not sit at the entry or exit of the hand-written BVH walk:
     that stretch runs once per leaf visit (7 - 8 times per pair), and 16 reloads there measured +9 % kernel time.  The build
-    leaves a report made from the compiler's own listing (tools/walk_asm_report.py); also pins the node test at 9 vector
+    leaves a report made from the compiler's own listing (daisyriot_amd/csrc/walk_asm_report.py); also pins the node test at 9 vector
     instructions."""
     path = os.path.join(ROOT, "daisyriot_amd", "lib", "geom_kernels.walk.txt")
     if not os.path.exists(path):
@@ -153,3 +155,6 @@ def test_tile_kernel_walk_has_no_spill_reloads_around_it():
     assert rep["kernel_found"] == "1" and rep["walk_blocks"] == "1"
     assert rep["walk_entry_spill_ops"] == "0" and rep["walk_exit_spill_ops"] == "0"
     assert rep["node_test_valu"] == "9"
+    assert rep["pairs_kernel_found"] == "1" and rep["pairs_walk_blocks"] == "1"
+    assert rep["pairs_walk_entry_spill_ops"] == "0" and rep["pairs_walk_exit_spill_ops"] == "0"
+    assert rep["pairs_node_test_valu"] == "9"

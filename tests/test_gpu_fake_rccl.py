@@ -25,10 +25,9 @@ def _bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-@pytest.mark.parametrize("world,S,n,rule", [(2, 8, 700, api.RULE_INTEGRAND), (3, 3, 2500, api.RULE_RECIPROCITY)])
-def test_ranks_in_separate_processes(world, S, n, rule, tmp_path):
+def _run_ranks(world, S, n, rule, tmp_path, **extra_env):
     subprocess.check_call(["make", "-C", FAKE_DIR], stdout=subprocess.DEVNULL)
-    env = dict(os.environ, DR_RCCL_LIB=FAKE, FAKE_RCCL_SLOT_MB="16")
+    env = dict(os.environ, DR_RCCL_LIB=FAKE, FAKE_RCCL_SLOT_MB="16", **extra_env)
     env.pop("DR_NO_VIS_EXCHANGE", None)
     id_file = str(tmp_path / "id.npy")
     procs = [subprocess.Popen([sys.executable, os.path.join(FAKE_DIR, "rank_main.py"), str(r), str(world), str(n), str(S), str(rule),
@@ -43,6 +42,15 @@ def test_ranks_in_separate_processes(world, S, n, rule, tmp_path):
                 q.kill()
             raise
         outs.append(o)
+    return procs, outs
+
+
+# (3, 3, 400): 400 patches in shards of 256 rows leave rank 2 WITHOUT rows -- it still has to take every decision of a
+# converge run with the others (the reference's 6400-patch scene on 8 GPUs has such a rank)
+@pytest.mark.parametrize("world,S,n,rule", [(2, 8, 700, api.RULE_INTEGRAND), (3, 3, 2500, api.RULE_RECIPROCITY),
+                                            (3, 3, 400, api.RULE_INTEGRAND)])
+def test_ranks_in_separate_processes(world, S, n, rule, tmp_path):
+    procs, outs = _run_ranks(world, S, n, rule, tmp_path)
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
     # the same scene on one context
@@ -63,6 +71,8 @@ def test_ranks_in_separate_processes(world, S, n, rule, tmp_path):
         Bc, Rc = c.read()
     ranks = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
     assert sum(int(d["traced"]) for d in ranks) == traced_once          # every pair traced by exactly one rank
+    if n == 400:
+        assert int(ranks[2]["nrows"]) == 0 and it > 8                   # an empty rank, and more than one batch of queued passes
     for d in ranks:
         row0, nrows = int(d["row0"]), int(d["nrows"])
         assert np.array_equal(d["V"], V[row0:row0 + nrows])
@@ -74,6 +84,14 @@ def test_ranks_in_separate_processes(world, S, n, rule, tmp_path):
         assert int(d["iters"]) == it                                     # all ranks stop at the same pass
         assert np.allclose(d["Bc"], Bc[row0:row0 + nrows], rtol=2e-6, atol=1e-12)
         assert np.array_equal(_bits(d["Rc"]), _bits(ranks[0]["Rc"]))
+
+
+def test_a_failing_rank_does_not_strand_its_peers(tmp_path):
+    """after the ranks agreed to start, rank 1's first assembly launch "fails" (DR_FAULT_ASSEMBLE_RANK): the second go / no-go
+    before the all-to-all turns that into an error on EVERY rank instead of peers waiting in the collective"""
+    procs, outs = _run_ranks(2, 3, 700, api.RULE_INTEGRAND, tmp_path, DR_FAULT_ASSEMBLE_RANK="1")
+    assert all(p.returncode != 0 for p in procs), [p.returncode for p in procs]
+    assert "injected failure" in outs[1] and "another rank failed" in outs[0], outs
 
 
 def test_bench_launches_its_own_ranks(tmp_path):

@@ -1,9 +1,10 @@
 #!/bin/bash
-# the three walks of k_ff_tiles: from the root (shipped), tile-pair shaft lists (DR_SHAFT=1), per-patch path records (DR_PATHS=1)
+# A/B of the two tile-kernel walks: threaded tree (round 2) against sibling-pair records; kernel ms at 16k and 64k patches,
+# node visits per pair from the counted (DR_TILE_STATS) build at 16k
 cd $GRAFT_REPO_ROOT
-for n in ${SIZES:-16384 65536}; do
-  for mode in "DR_SHAFT=0 DR_PATHS=0" "DR_SHAFT=1" "DR_PATHS=1"; do
-    [ $n -le 16384 ] && env $mode NPATCH=$n DR_TILE_STATS=1 timeout -k 10 300 python3 tools/asm_one.py 2>&1 | grep -E "daisyriot" | sed "s/^/$mode /"
-    env $mode NPATCH=$n timeout -k 10 300 python3 tools/asm_one.py 2>&1 | grep RES | sed "s/^/$mode /"
+for w in threaded pairs; do
+  for n in 16384 65536; do
+    for rep in 1 2; do DR_WALK=$w NPATCH=$n timeout -k 10 120 python3 tools/asm_one.py 2>&1 | sed "s/^/$w /"; done
   done
+  DR_WALK=$w DR_TILE_STATS=1 NPATCH=16384 timeout -k 10 200 python3 tools/asm_one.py 2>&1 | sed "s/^/$w stats /"
 done
