@@ -124,6 +124,22 @@ def bare_read_gbs():
     return None, None
 
 
+def device_report(torch, index):
+    """name, size and clocks of the GPU the numbers were taken on (clocks: what rocm-smi shows right now, best effort)"""
+    p = torch.cuda.get_device_properties(index)
+    d = {"name": p.name, "compute_units": p.multi_processor_count, "memory_GB": round(p.total_memory / 1e9, 1),
+         "max_clock_MHz": getattr(p, "clock_rate", 0) / 1e3 or None, "arch": getattr(p, "gcnArchName", None)}
+    try:
+        import subprocess
+        r = subprocess.run(["rocm-smi", "-d", str(index), "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+        j = json.loads(r.stdout)
+        card = next(iter(j.values()))
+        d["clocks_now"] = {k: v for k, v in card.items() if "clock" in k.lower() and ("sclk" in k.lower() or "mclk" in k.lower() or "fclk" in k.lower())}
+    except Exception as e:                                      # no rocm-smi / another output format: the name is what matters
+        d["clocks_now"] = "unavailable (%s)" % type(e).__name__
+    return d
+
+
 def strided_rows(N, n):
     """n rows spread over the whole matrix (every wall and both inner boxes of the Cornell scene), not the first few"""
     step = N / float(n)
@@ -171,12 +187,11 @@ def cpu_baselines(ctx, sc, uv, n_rows_sweep, n_rows_ff):
     m = ob.Mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
     rows = strided_rows(N, n_rows_ff)
     t = time.perf_counter()
-    for r in rows:
-        ob.assemble_rows(m, uv, row0=r, nrows=1, want_vis=False, threads=1, bvh=True)
+    ob.assemble_row_list(m, uv, rows, threads=1)
     dt2 = time.perf_counter() - t
     ff = {"value": len(rows) * (N - 1) / dt2, "unit": "pairs/s", "cores": 1, "kind": "port",
           "sample": "%d rows spread over the matrix (%s) x %d columns, integrand + %d rays per facing pair through the "
-                    "oracle's BVH (rebuilt per row: included), %.1f s" % (len(rows), ",".join(map(str, rows)), N, uv.shape[0], dt2)}
+                    "oracle's BVH (built once for the sample: included), %.1f s" % (len(rows), ",".join(map(str, rows)), N, uv.shape[0], dt2)}
     # the same two samples with OpenMP over rows on every host core (the reference itself has no threading)
     # (a one-GPU box grants about 16 host CPUs however many the machine has: more threads only thrash)
     cores = max(1, min(ob.num_threads(), len(os.sched_getaffinity(0)), 16))
@@ -268,6 +283,9 @@ def main():
                          "of the multi-process code path on a one-GPU box")
     ap.add_argument("--group", action="store_true",
                     help="one process drives all --gpus devices through the library's dr_group (no torch.distributed)")
+    ap.add_argument("--group-exchange", choices=["p2p", "rccl", "inpass"], default=None,
+                    help="--group: how the residual travels after a pass (dr_options::group_exchange; default: RCCL between distinct "
+                         "devices, peer copies between ranks that share one)")
     ap.add_argument("--devices", type=str, default=None,
                     help="with --group: the HIP ordinals, e.g. 0,1,2,3 (the same ordinal several times rehearses on one GPU)")
     args = ap.parse_args()
@@ -446,6 +464,12 @@ def main():
                        "launch": "one process per GPU (torch.distributed / RCCL)" if not rehearsal else
                                  "REHEARSAL, not a measurement: %d processes share GPU 0, gloo + tests/fake_rccl" % world},
             "rehearsal_on_shared_gpu": bool(rehearsal),
+            "device": device_report(torch, local_rank),
+            # the options this run ran with (dr_options: defaults + DR_* environment) and what the library made of them
+            "options": ctx.options().as_dict(),
+            "used": {"tree": {1: "lbvh", 2: "sah"}.get(info.tree_used), "tree_built_on": "host" if info.tree_on_host else "device",
+                     "tree_depth": int(info.tree_depth), "walk": {1: "threaded", 2: "pairs", 3: "paths"}.get(info.walk_used),
+                     "sweep_ksplit": int(info.sweep_ksplit)},
             # what every rank's RCCL communicator itself reports (ncclCommCount / ncclCommUserRank): 0 = no communicator
             "rccl_world": int(per[0][3]), "rccl_ranks": [int(p[4]) for p in per],
             "exchange_us_per_pass": (dt / args.steps * 1e3 - max(p[1] for p in per)) * 1e3,
@@ -456,8 +480,8 @@ def main():
                          "frac_of_bare_read": achieved / bare if bare else None,
                          "launches_timed": int(info.sweep_launches), "per_rank": per_rank,
                          "note": "per rank: that rank's algorithmic shard bytes / its hipEvent-timed kernel; slowest rank shown"},
-            # seconds = the BVH build (inside dr_scene_set_mesh: tree topology on the host, bounds and layout on the device)
-            # + dr_formfactors_assemble, as SURVEY.md 8(d) defines t_assemble
+            # seconds = the BVH build (inside dr_scene_set_mesh; all of it on the device) + dr_formfactors_assemble, as
+            # SURVEY.md 8(d) defines t_assemble
             "formfactors": {"value": N * (N - 1) / (t_asm + t_bvh), "unit": "pairs/s", "seconds": t_asm + t_bvh,
                             "kernel_seconds": t_asm_kernel, "bvh_build_seconds": t_bvh,
                             "pairs_traced": pairs_traced, "rays_per_s": pairs_traced * args.rays / (t_asm + t_bvh),
@@ -500,6 +524,8 @@ def run_group(args, json_fd):
     E = sc.emission(7.0)
     N, S = sc.N, sc.S
     g = api.Group(devices)
+    if args.group_exchange:
+        g.set_options(group_exchange={"p2p": api.GROUP_EXCHANGE_P2P, "rccl": api.GROUP_EXCHANGE_RCCL, "inpass": api.GROUP_EXCHANGE_INPASS}[args.group_exchange])
     g.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
     t0 = time.perf_counter()
     g.assemble(uv, rule=api.RULE_INTEGRAND)
@@ -534,9 +560,15 @@ def run_group(args, json_fd):
         "config": {"workload": "subdivided Cornell box, %d patches, %d spectral bins, K=%d rays/pair, dense fp32 F row-sharded "
                                "over %d rank(s) of ONE process (dr_group)" % (N, S, args.rays, len(devices)),
                    "patches": N, "bins": S, "rays_per_pair": args.rays, "rows_per_gpu": [q["rows"] for q in per_rank],
-                   "devices": devices, "launch": "one process, dr_group; exchange: %s" % ("RCCL (ncclCommInitAll)" if g.uses_rccl() else "peer copies"),
+                   "devices": devices, "launch": "one process, dr_group; exchange: %s" % ("RCCL (ncclCommInitAll)" if g.uses_rccl() else
+                                                                                         ("in the pass (peer stores + gate kernel)" if args.group_exchange == "inpass" else "peer copies")),
                    "rehearsal_on_shared_gpu": shared},
         "rccl_world": len(devices) if g.uses_rccl() else 0,
+        "device": device_report(torch, devices[0]),
+        "options": g.ranks[0].options().as_dict(),
+        # what a pass costs beyond its kernel: wall time per step minus the ranks' kernel time (ranks that share a GPU run one
+        # after the other: the sum; ranks on their own GPUs side by side: the slowest)
+        "exchange_us_per_pass": (dt / args.steps * 1e3 - (sum(q["kernel_ms_avg"] for q in per_rank) if shared else max(q["kernel_ms_avg"] for q in per_rank))) * 1e3,
         "roofline": {"bound": "hbm", "kernel": "k_sweep", "achieved": slow["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": slow["GBs"] / HBM_PEAK_GBS, "traffic": None,
                      "traffic_source": "not collected for the group path",

@@ -37,7 +37,12 @@ EXPORTS = [
     "dr_group_assemble", "dr_group_solver_init", "dr_group_solver_step", "dr_group_solver_converge",
     "dr_group_solver_reset", "dr_group_solver_read", "dr_group_synchronize",
     "dr_comm_set_library", "dr_comm_library_info",
+    "dr_options_defaults", "dr_set_options", "dr_get_options", "dr_group_set_options",
 ]
+
+TREE_AUTO, TREE_LBVH, TREE_SAH = 0, 1, 2
+WALK_AUTO, WALK_THREADED, WALK_PAIRS, WALK_PATHS = 0, 1, 2, 3
+GROUP_EXCHANGE_AUTO, GROUP_EXCHANGE_P2P, GROUP_EXCHANGE_RCCL, GROUP_EXCHANGE_INPASS = 0, 1, 2, 3
 
 
 class DaisyRiotError(RuntimeError):
@@ -49,7 +54,23 @@ class Info(C.Structure):
                 ("nrows", C.c_int), ("rows_per_rank", C.c_int), ("n_bvh_nodes", C.c_int),
                 ("ld_F", C.c_size_t), ("bytes_F", C.c_size_t), ("last_assemble_ms", C.c_double),
                 ("last_bvh_ms", C.c_double), ("pairs_traced", C.c_uint64), ("sweep_launches", C.c_uint64),
-                ("sweep_ms_total", C.c_double), ("blocks_nonzero", C.c_uint64), ("blocks_total", C.c_uint64)]
+                ("sweep_ms_total", C.c_double), ("blocks_nonzero", C.c_uint64), ("blocks_total", C.c_uint64),
+                ("tree_used", C.c_int32), ("tree_on_host", C.c_int32), ("tree_depth", C.c_int32), ("walk_used", C.c_int32),
+                ("sweep_ksplit", C.c_int32), ("reserved_", C.c_int32)]
+
+
+class Options(C.Structure):
+    """dr_options (include/daisyriot_hip.h): every choice between equivalent ways of doing the same thing, per context."""
+    _fields_ = [("size", C.c_int32), ("tree", C.c_int32), ("sah_on_host", C.c_int32), ("morton_key", C.c_int32),
+                ("sah_bins", C.c_int32), ("sah_dilate", C.c_float), ("sah_host_threads", C.c_int32),
+                ("walk", C.c_int32), ("octant_test", C.c_int32), ("vis_exchange", C.c_int32), ("tile_stats", C.c_int32),
+                ("debug_pair_lo", C.c_int32), ("debug_pair_hi", C.c_int32), ("debug_ray", C.c_int32),
+                ("sweep_ksplit", C.c_int32), ("sweep_taper", C.c_int32), ("sweep_rows_per_wave", C.c_int32),
+                ("sweep_skew", C.c_int32), ("sweep_mfma", C.c_int32), ("sweep_fenced", C.c_int32), ("no_comm", C.c_int32),
+                ("debug_converge", C.c_int32), ("group_exchange", C.c_int32), ("fault_assemble_rank", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "size"}
 
 
 _lib = None
@@ -150,6 +171,10 @@ def load_library(path=None):
     L.dr_solver_skip_zero_blocks.argtypes = [vp, i]
     L.dr_display_patch_colors.argtypes = [vp, i, vp, vp]
     L.dr_display_vertex_colors.argtypes = [vp, vp, vp, vp, i, vp]
+    L.dr_options_defaults.argtypes = [C.POINTER(Options)]
+    L.dr_set_options.argtypes = [vp, C.POINTER(Options)]
+    L.dr_get_options.argtypes = [vp, C.POINTER(Options)]
+    L.dr_group_set_options.argtypes = [vp, C.POINTER(Options)]
     for name in EXPORTS:
         if name not in ("dr_last_error", "dr_residual_offset", "dr_residual_chunk_floats"):
             getattr(L, name).restype = i
@@ -198,6 +223,15 @@ def vis_exchange_fits(N, world, keep_visibility, device_bytes):
     """does a world-way assembly take the ray-count exchange path on cards of device_bytes?  (no rank argument: every
     rank must decide alike) -- pure host arithmetic of the library"""
     return bool(load_library().dr_vis_exchange_fits(int(N), int(world), int(bool(keep_visibility)), int(device_bytes)))
+
+
+def options_defaults():
+    """the built-in defaults overridden by the DR_* environment variables (what a new context starts with)"""
+    L = load_library()
+    o = Options()
+    if L.dr_options_defaults(C.byref(o)):
+        raise DaisyRiotError("dr_options_defaults: %s" % L.dr_last_error().decode())
+    return o
 
 
 def comm_library_info():
@@ -274,6 +308,21 @@ class Context:
         self.close()
 
     # -- configuration
+    def options(self):
+        o = Options()
+        self._chk(self.L.dr_get_options(self.h, C.byref(o)), "dr_get_options")
+        return o
+
+    def set_options(self, **kw):
+        """change some of the context's options (names as in dr_options); returns the full set now in force"""
+        o = self.options()
+        for k, v in kw.items():
+            if k not in dict(Options._fields_) or k == "size":
+                raise DaisyRiotError("no option %r" % k)
+            setattr(o, k, v)
+        self._chk(self.L.dr_set_options(self.h, C.byref(o)), "dr_set_options")
+        return o
+
     def set_stream(self, hip_stream_ptr):
         self._chk(self.L.dr_set_stream(self.h, C.c_void_p(hip_stream_ptr)), "dr_set_stream")
 
@@ -513,6 +562,16 @@ class Group:
         n, u = C.c_int(), C.c_int()
         self._chk(self.L.dr_group_info(self.h, C.byref(n), C.byref(u)), "dr_group_info")
         return bool(u.value)
+
+    def set_options(self, **kw):
+        """the same options on every rank (group_exchange: how the residual travels after a pass)"""
+        o = self.ranks[0].options()
+        for k, v in kw.items():
+            if k not in dict(Options._fields_) or k == "size":
+                raise DaisyRiotError("no option %r" % k)
+            setattr(o, k, v)
+        self._chk(self.L.dr_group_set_options(self.h, C.byref(o)), "dr_group_set_options")
+        return o
 
     def set_mesh(self, vertices, normals, tri_v, tri_n):
         v, n = _f32(vertices).reshape(-1, 3), _f32(normals).reshape(-1, 3)

@@ -26,6 +26,59 @@ int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
+// the built-in defaults, overridden by the environment -- the ONLY place the library reads it (DR_RCCL_LIB apart: the RCCL
+// binding is per process, dr_comm.cpp)
+void options_from_env(dr_options* o) {
+    std::memset(o, 0, sizeof *o);
+    o->size = (int32_t)sizeof *o;
+    auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; };
+    auto is = [](const char* name, const char* v) { const char* e = getenv(name); return e && !strcmp(e, v); };
+    o->tree = is("DR_BVH", "lbvh") ? DR_TREE_LBVH : (is("DR_BVH", "sah") ? DR_TREE_SAH : DR_TREE_AUTO);
+    o->sah_on_host = geti("DR_SAH_HOST", 0) != 0;
+    o->morton_key = geti("DR_BVH_KEY", 0);
+    o->sah_bins = geti("DR_SAH_BINS", 32);
+    { const char* e = getenv("DR_SAH_DILATE"); o->sah_dilate = e && *e ? (float)atof(e) : 0.5f; }
+    o->sah_host_threads = geti("DR_SAH_THREADS", 0);
+    o->walk = is("DR_WALK", "threaded") ? DR_WALK_THREADED : (is("DR_WALK", "pairs") ? DR_WALK_PAIRS : (is("DR_WALK", "paths") ? DR_WALK_PATHS : DR_WALK_AUTO));
+    o->octant_test = geti("DR_OCTANT", 1) != 0;
+    o->vis_exchange = getenv("DR_NO_VIS_EXCHANGE") ? 1 : (getenv("DR_VIS_EXCHANGE_REHEARSE") ? 2 : 0);
+    o->tile_stats = getenv("DR_TILE_STATS") ? 1 : 0;
+    o->debug_pair_lo = o->debug_pair_hi = -1; o->debug_ray = 0;
+    if (const char* dp = getenv("DR_DEBUG_PAIR")) sscanf(dp, "%d,%d,%d", &o->debug_pair_lo, &o->debug_pair_hi, &o->debug_ray);
+    o->sweep_ksplit = std::max(geti("DR_SWEEP_KSPLIT", 0), 0);
+    o->sweep_taper = geti("DR_SWEEP_TAPER", -1);
+    o->sweep_rows_per_wave = geti("DR_SWEEP_RR", 0);
+    o->sweep_skew = geti("DR_SWEEP_SKEW", -1);
+    o->sweep_mfma = geti("DR_SWEEP_MFMA", 1) != 0;
+    o->sweep_fenced = geti("DR_SWEEP_FENCED", 0) != 0;
+    o->no_comm = getenv("DR_NO_COMM") ? 1 : 0;
+    o->debug_converge = getenv("DR_DEBUG_CONV") ? 1 : 0;
+    o->group_exchange = is("DR_GROUP_EXCHANGE", "p2p") ? DR_GROUP_EXCHANGE_P2P : (is("DR_GROUP_EXCHANGE", "rccl") ? DR_GROUP_EXCHANGE_RCCL
+                        : (is("DR_GROUP_EXCHANGE", "inpass") ? DR_GROUP_EXCHANGE_INPASS : DR_GROUP_EXCHANGE_AUTO));
+    o->fault_assemble_rank = geti("DR_FAULT_ASSEMBLE_RANK", -1);
+}
+
+int check_options(const dr_options* o) {
+    if (!o) return fail(DR_ERR_INVALID, "options is null");
+    if (o->size != (int32_t)sizeof(dr_options)) return fail(DR_ERR_INVALID, "dr_options of %d bytes, the library's is %zu: start from dr_options_defaults", o->size, sizeof(dr_options));
+    if (o->tree < DR_TREE_AUTO || o->tree > DR_TREE_SAH) return fail(DR_ERR_INVALID, "options: tree %d", o->tree);
+    if (o->walk < DR_WALK_AUTO || o->walk > DR_WALK_PATHS) return fail(DR_ERR_INVALID, "options: walk %d", o->walk);
+    if (o->morton_key < 0 || o->morton_key > 2) return fail(DR_ERR_INVALID, "options: morton_key %d", o->morton_key);
+    if (o->sah_bins < 2 || o->sah_bins > 128) return fail(DR_ERR_INVALID, "options: sah_bins %d outside 2..128", o->sah_bins);
+    if (!(o->sah_dilate >= 0.0f) || !(o->sah_dilate < 1e6f)) return fail(DR_ERR_INVALID, "options: sah_dilate %g", (double)o->sah_dilate);
+    if (o->sweep_ksplit < 0 || o->sweep_ksplit > 64) return fail(DR_ERR_INVALID, "options: sweep_ksplit %d outside 0..64", o->sweep_ksplit);
+    if (o->sweep_rows_per_wave != 0 && o->sweep_rows_per_wave != 4 && o->sweep_rows_per_wave != 8) return fail(DR_ERR_INVALID, "options: sweep_rows_per_wave %d (0, 4 or 8)", o->sweep_rows_per_wave);
+    if (o->group_exchange < DR_GROUP_EXCHANGE_AUTO || o->group_exchange > DR_GROUP_EXCHANGE_INPASS) return fail(DR_ERR_INVALID, "options: group_exchange %d", o->group_exchange);
+    if (o->vis_exchange < 0 || o->vis_exchange > 2) return fail(DR_ERR_INVALID, "options: vis_exchange %d", o->vis_exchange);
+    return DR_OK;
+}
+
+SweepTuning sweep_tuning(const dr_options& o) {
+    SweepTuning t;
+    t.rows_per_wave = o.sweep_rows_per_wave; t.mfma = o.sweep_mfma; t.ksplit = o.sweep_ksplit; t.skew = o.sweep_skew; t.taper = o.sweep_taper;
+    t.fenced = o.sweep_fenced;
+    return t;
+}
 }  // namespace
 
 #define HIPCHK(x)                                                                                   \
@@ -66,7 +119,7 @@ struct dr_context {
     BvhNode* d_path_rec = nullptr;    // [N][PATH_RECS] path records of the patches (PathHdr, dr_internal.h)
     PathHdr* d_path_hdr = nullptr;
     int n_nodes = 0;
-    float scene_span = 0;     // max |coordinate| + diagonal of the scene (scale of the shaft culling's tolerances)
+    float scene_span = 0;     // max |coordinate| + diagonal of the scene
     // shard
     int rpr = 0, row0 = 0, nrows = 0;
     size_t ldF = 0;
@@ -95,8 +148,14 @@ struct dr_context {
     size_t cstride = 0;               // floats per rank chunk of the residual buffers: S*rpr + RTAIL (the chunk's per-bin sums)
     unsigned* d_tickets = nullptr;    // in-launch reductions of the pass (SweepParams::tickets)
     double* d_blk_sums = nullptr;
-    int* d_ctl = nullptr;             // [0] passes done, [1] a pass found the residual converged (SweepParams::ctl)
-    int fault_assemble_rank = -1;     // tests: the rank whose first assembly launch "fails" (DR_FAULT_ASSEMBLE_RANK, read at creation)
+    int* d_ctl = nullptr;             // [0] passes done, [1] a pass found the residual converged (SweepParams::ctl), [3] a gate timed out
+    // in-pass exchange of a group (dr_options::group_exchange = INPASS): the ranks' published pass numbers as seen by this
+    // device, the number of passes launched since the last reset, and the group's contexts (set by the group, else empty)
+    unsigned* d_seq = nullptr;
+    unsigned pass_seq = 0;
+    std::vector<dr_context*> inpass_peers;
+    dr_options opt;                   // every choice between equivalent ways (include/daisyriot_hip.h): defaults + environment at creation
+    int tree_used = 0, tree_on_host = 0, walk_used = 0;      // what the last set_mesh / assembly really did (dr_get_info)
     int check_every = 8;              // dr_solver_converge looks at d_ctl once per this many queued passes
     bool tails_valid = false;         // the current residual's chunk tails hold its per-bin sums
     // optional zero-block skipping of the light pass (dr_solver_skip_zero_blocks)
@@ -138,8 +197,8 @@ void free_F(dr_context* c) {
 void free_solver(dr_context* c) {
     hipFree(c->d_M); hipFree(c->d_E); hipFree(c->d_B); hipFree(c->d_R[0]); hipFree(c->d_R[1]);
     hipFree(c->d_mat); hipFree(c->d_Gpart); c->d_Gpart = nullptr; hipFree(c->d_stage); c->d_stage = nullptr;
-    hipFree(c->d_tickets); hipFree(c->d_blk_sums); hipFree(c->d_ctl);
-    c->d_tickets = nullptr; c->d_blk_sums = nullptr; c->d_ctl = nullptr;
+    hipFree(c->d_tickets); hipFree(c->d_blk_sums); hipFree(c->d_ctl); hipFree(c->d_seq);
+    c->d_tickets = nullptr; c->d_blk_sums = nullptr; c->d_ctl = nullptr; c->d_seq = nullptr; c->pass_seq = 0;
     hipFree(c->d_rgb); c->d_rgb = nullptr; c->have_rgb = false;
     hipFree(c->d_voff); hipFree(c->d_vadj); hipFree(c->d_vout); hipFree(c->d_vin);
     c->d_voff = c->d_vadj = nullptr; c->d_vout = c->d_vin = nullptr; c->voff_n = c->vadj_n = c->vout_n = c->vin_n = 0;
@@ -236,6 +295,22 @@ int sweep_once(dr_context* c, int conv_mode = 0, float thr = 0.0f) {
         c->tails_valid = true;
     }
     if (conv_mode == 0) c->tails_valid = false;
+    p.tune = sweep_tuning(c->opt);
+    p.n_peers = 0; p.seq = 0;
+    for (int q = 0; q < MAX_GROUP; q++) { p.peers[q] = nullptr; p.peer_seq[q] = nullptr; }
+    if (!c->inpass_peers.empty()) {
+        // in-pass exchange: this pass stores its chunk into every peer's buffer of the same parity and publishes its number;
+        // it starts behind a gate that waits until every rank has published the previous pass
+        p.n_peers = (int)c->inpass_peers.size();
+        for (int q = 0; q < p.n_peers; q++) {
+            dr_context* pc = c->inpass_peers[q];
+            p.peers[q] = pc == c ? nullptr : pc->d_R[c->cur ^ 1];
+            p.peer_seq[q] = pc->d_seq;
+        }
+        p.seq = c->pass_seq + 1;
+        if (c->pass_seq > 0) HIPCHK(launch_wait_peers(c->stream, c->d_seq, c->world, c->pass_seq, c->d_ctl + 3));
+        c->pass_seq++;
+    }
     p.tile_mask = nullptr; p.mask_words = 0;
     if (c->skip_zero) {
         if (!c->mask_valid) { int rc = build_tile_mask(c); if (rc) return rc; }
@@ -260,7 +335,7 @@ int sweep_once(dr_context* c, int conv_mode = 0, float thr = 0.0f) {
     }
     HIPCHK(launch_sweep(c->stream, p));
     if (c->profile) HIPCHK(hipEventRecord(e1, c->stream));
-    if (c->comm.comm) {
+    if (c->comm.comm && !c->manual_exchange) {
         std::string err = comm_allgather_inplace(c->comm, c->d_R[c->cur ^ 1], c->cstride, c->stream);
         if (!err.empty()) return fail(DR_ERR_COMM, "%s", err.c_str());
     }
@@ -303,10 +378,34 @@ int dr_context_create(int device_id, dr_context** out) {
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(DR_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
-    if (const char* fe = getenv("DR_FAULT_ASSEMBLE_RANK")) c->fault_assemble_rank = atoi(fe);
+    options_from_env(&c->opt);
     e = hipMalloc(&c->d_counter, 16 * sizeof(unsigned long long));
     if (e != hipSuccess) { hipStreamDestroy(c->own_stream); delete c; return fail(DR_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
     *out = c;
+    return DR_OK;
+}
+
+int dr_options_defaults(dr_options* out) {
+    if (!out) return fail(DR_ERR_INVALID, "out is null");
+    options_from_env(out);
+    return DR_OK;
+}
+
+int dr_set_options(dr_context* c, const dr_options* o) {
+    CTX(c);
+    int rc = check_options(o);
+    if (rc) return rc;
+    // a solver that was laid out under other pass options keeps them until the next dr_solver_init: the buffers depend on them
+    if (c->have_solver && (o->sweep_ksplit != c->opt.sweep_ksplit || o->sweep_rows_per_wave != c->opt.sweep_rows_per_wave || o->sweep_mfma != c->opt.sweep_mfma))
+        return fail(DR_ERR_STATE, "the pass layout options (sweep_ksplit, sweep_rows_per_wave, sweep_mfma) cannot change under an initialised solver: set them before dr_solver_init");
+    c->opt = *o;
+    return DR_OK;
+}
+
+int dr_get_options(dr_context* c, dr_options* out) {
+    CTX(c);
+    if (!out) return fail(DR_ERR_INVALID, "out is null");
+    *out = c->opt;
     return DR_OK;
 }
 
@@ -415,9 +514,10 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     HIPCHK(hipMalloc(&c->d_bvh_lh, sizeof(BvhNode) * ((size_t)c->n_nodes + 2)));
     HIPCHK(hipMalloc(&c->d_pairs, sizeof(BvhPair) * (size_t)std::max(N - 1, 1)));
     HIPCHK(hipMalloc(&c->d_pairs_lh, sizeof(BvhPair) * (size_t)std::max(N - 1, 1)));
-    // the per-patch path records (1 KiB per patch) are only built for the experimental walk that uses them (DR_PATHS=1)
-    if (const char* e = getenv("DR_PATHS"); e && atoi(e) != 0) {
-        HIPCHK(hipMalloc(&c->d_path_rec, sizeof(BvhNode) * (size_t)N * PATH_RECS));
+    // the per-patch path records (PATH_RECS x 32 B per patch; their byte offsets must fit 32 bits) only for the walk that
+    // streams them (dr_options::walk = PATHS: exact, measured no faster -- profiles/r03/assembly_notes.md)
+    if (c->opt.walk == DR_WALK_PATHS && (double)N * PATH_RECS * sizeof(BvhNode) < 4.0e9) {
+        HIPCHK(hipMalloc(&c->d_path_rec, sizeof(BvhNode) * ((size_t)N * PATH_RECS + 1)));
         HIPCHK(hipMalloc(&c->d_path_hdr, sizeof(PathHdr) * (size_t)N));
     }
     HIPCHK(hipMemcpyAsync(c->d_vtx, vertices, sizeof(float) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream));
@@ -428,8 +528,14 @@ int dr_scene_set_mesh(dr_context* c, const float* vertices, int V, const float* 
     EventPair ev;
     HIPCHK(ev.create());
     HIPCHK(hipEventRecord(ev.a, c->stream));
+    TreeOptions topt;
+    topt.sah = c->opt.tree == DR_TREE_SAH || (c->opt.tree == DR_TREE_AUTO && N >= 6144);
+    topt.sah_on_host = c->opt.sah_on_host != 0;
+    topt.morton_key = c->opt.morton_key; topt.sah_bins = c->opt.sah_bins; topt.sah_dilate = c->opt.sah_dilate; topt.sah_host_threads = c->opt.sah_host_threads;
+    c->tree_used = topt.sah ? DR_TREE_SAH : DR_TREE_LBVH;
+    c->tree_on_host = topt.sah && topt.sah_on_host;
     hipError_t be = build_lbvh(c->stream, N, c->d_tri, lo, hi, node_pad, c->d_bvh, c->d_bvh_lh, c->d_tri_sorted, &c->n_nodes, c->d_path_rec, c->d_path_hdr,
-                               c->shared_sah, c->d_pairs, c->d_pairs_lh, &c->tree_depth);
+                               topt, c->shared_sah, c->d_pairs, c->d_pairs_lh, &c->tree_depth);
     if (be != hipSuccess) return fail(DR_ERR_DEVICE, "LBVH build failed: %s", hipGetErrorString(be));
     HIPCHK(hipEventRecord(ev.b, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -499,26 +605,22 @@ static int assemble_launch(dr_context* c, int K, float eps, int rule, int trace,
         p.row0 = c->row0; p.nrows = c->nrows; p.n_nodes = c->n_nodes; p.eps = eps; p.ldF = c->ldF;
         p.F = c->d_F; p.vis = c->d_vis; p.patch = c->d_patch; p.tri = c->d_tri; p.tri_sorted = c->d_tri_sorted; p.bvh = c->d_bvh;
         p.uv = c->d_uv; p.pairs_traced = c->d_counter;
-        // DR_OCTANT=0: the general node test for every pair (A/B runs)
-        { const char* e = getenv("DR_OCTANT"); p.bvh_lh = (e && !atoi(e)) ? nullptr : c->d_bvh_lh; }
-        // the walk: over the sibling-pair records unless the tree is deeper than its stack (or DR_WALK=threaded)
-        { const char* e = getenv("DR_WALK"); const bool pw = !(e && !strcmp(e, "threaded")) && c->tree_depth <= PAIR_STACK - 2;
-          p.pairs = pw ? c->d_pairs : nullptr; p.pairs_lh = (pw && p.bvh_lh) ? c->d_pairs_lh : nullptr; }
-        // DR_PATHS=1: the pairs' walks run over the two patches' path records instead of starting at the root (exact, measured
-        // slower: profiles/r02/assembly_notes.md)
-        { const char* e = getenv("DR_PATHS"); const bool on = (e ? atoi(e) != 0 : false) && c->d_path_rec && c->d_path_hdr;
+        // dr_options::octant_test = 0: the general node test for every pair (A/B runs)
+        p.bvh_lh = c->opt.octant_test ? c->d_bvh_lh : nullptr;
+        // the walk: over the sibling-pair records unless the tree is deeper than its stack (one item per level; with path
+        // records up to one per level of each of the two paths) or the options say threaded
+        const bool deep = 2 * c->tree_depth > PAIR_STACK - 2;
+        const bool pw = c->opt.walk != DR_WALK_THREADED && !deep;
+        p.pairs = pw ? c->d_pairs : nullptr; p.pairs_lh = (pw && p.bvh_lh) ? c->d_pairs_lh : nullptr;
+        // ... its stack filled from the two patches' path records when those were built (dr_options::walk = PATHS at set_mesh)
+        { const bool on = pw && c->opt.walk == DR_WALK_PATHS && c->d_path_rec && c->d_path_hdr;
           p.path_rec = on ? c->d_path_rec : nullptr; p.path_hdr = on ? c->d_path_hdr : nullptr; }
+        c->walk_used = !pw ? DR_WALK_THREADED : (p.path_hdr ? DR_WALK_PATHS : DR_WALK_PAIRS);
         p.vx_mode = vx_mode; p.vx_rank = c->rank; p.vx_tiles_per_rank = c->rpr / TILE; p.vsend = c->d_vsend; p.vrecv = c->d_vrecv;
-        // tile-pair shaft culling (geom_kernels.hip), off unless DR_SHAFT=1: exact, but measured slower than walks from
-        // the root (profiles/r02/assembly_notes.md); DR_SHAFT_MIN = nodes below which a subtree is listed whole
-        { const char* e = getenv("DR_SHAFT"); p.shaft = e ? atoi(e) : 0; }
-        { const char* e = getenv("DR_SHAFT_MIN"); p.shaft_min_bytes = (e ? atoi(e) : 128) * (int)sizeof(BvhNode); }
-        { const char* e = getenv("DR_SHAFT_SHRINK"); p.shaft_near_shrink = e ? (float)atof(e) : 0.25f; }
-        p.shaft_pad_ray = 1e-6f * c->scene_span; p.shaft_pad_node = 5e-6f * c->scene_span; p.shaft_tol = c->scene_span;
         p.ts_max = c->scene_span > 1e-19f ? std::min(1e19f / c->scene_span, 1e18f) : 1e18f;
-        p.stats = getenv("DR_TILE_STATS") ? 1 : 0;
-        p.dbg_lo = p.dbg_hi = -1;
-        if (const char* dp = getenv("DR_DEBUG_PAIR")) { p.stats = 1; p.dbg_ray = 0; sscanf(dp, "%d,%d,%d", &p.dbg_lo, &p.dbg_hi, &p.dbg_ray); }
+        p.stats = c->opt.tile_stats ? 1 : 0;
+        p.dbg_lo = c->opt.debug_pair_lo; p.dbg_hi = c->opt.debug_pair_hi; p.dbg_ray = c->opt.debug_ray;
+        if (p.dbg_lo >= 0) p.stats = 1;
         HIPCHK(launch_ff_tiles(c->stream, p));
     }
     HIPCHK(hipEventRecord(c->asm_ev->b, c->stream));
@@ -533,14 +635,13 @@ static int assemble_complete(dr_context* c, int vx_mode) {
     c->last_assemble_ms = (vx_mode == 2 ? c->last_assemble_ms : 0.0) + (c->asm_ev ? c->asm_ev->ms() : 0.0);
     delete c->asm_ev; c->asm_ev = nullptr;
     c->pairs_traced = cnt[0]; c->stat_visits = cnt[1]; c->stat_leaves = cnt[2];
-    if (getenv("DR_DEBUG_PAIR"))
+    if (c->opt.debug_pair_lo >= 0)
         fprintf(stderr, "[daisyriot] debug pair: live mask after target test %016llx, final %016llx; blocker of the debug ray: patch %lld "
                         "t %08llx tmax %08llx node %llu\n", cnt[1], cnt[3], (long long)cnt[4], cnt[5], cnt[6], cnt[7]);
-    else if (getenv("DR_TILE_STATS"))
-        fprintf(stderr, "[daisyriot] pairs %llu, node visits %llu (%.1f/pair), leaf tests %llu (%.1f/pair); shaft lists: %llu tile pairs, "
-                        "%.1f ranges and %.1f nodes looked at per list, %llu pairs walked from the root; path records streamed %.1f/pair\n", cnt[0], cnt[1],
-                cnt[0] ? (double)cnt[1] / cnt[0] : 0.0, cnt[2], cnt[0] ? (double)cnt[2] / cnt[0] : 0.0, cnt[11],
-                cnt[11] ? (double)cnt[8] / cnt[11] : 0.0, cnt[11] ? (double)cnt[9] / cnt[11] : 0.0, cnt[10], cnt[0] ? (double)cnt[12] / cnt[0] : 0.0);
+    else if (c->opt.tile_stats)
+        fprintf(stderr, "[daisyriot] pairs %llu, node visits %llu (%.1f/pair), leaf tests %llu (%.1f/pair); path records streamed %.1f/pair; "
+                        "waves with mixed octants %llu; tree depth %d\n", cnt[0], cnt[1], cnt[0] ? (double)cnt[1] / cnt[0] : 0.0, cnt[2],
+                cnt[0] ? (double)cnt[2] / cnt[0] : 0.0, cnt[0] ? (double)cnt[12] / cnt[0] : 0.0, cnt[13], c->tree_depth);
     if (vx_mode == 1) {
         c->split_pending = true;
     } else {
@@ -600,8 +701,8 @@ int dr_formfactors_assemble(dr_context* c, const float* uv, int K, float eps, in
     if (!c) return fail(DR_ERR_INVALID, "null context");
     // several ranks joined by RCCL: every pair between two ranks' rows is traced by one of them only and its 64 x 64
     // ray counts travel to the other (one all-to-all of slot blocks); otherwise the rank is self-sufficient
-    // (DR_VIS_EXCHANGE_REHEARSE: take this path with a single-rank communicator too -- a one-GPU rehearsal of the calls)
-    bool exchange = (c->world > 1 || getenv("DR_VIS_EXCHANGE_REHEARSE")) && c->comm.comm && !getenv("DR_NO_VIS_EXCHANGE");
+    // (dr_options::vis_exchange = 2: take this path with a single-rank communicator too -- a one-GPU rehearsal of the calls)
+    bool exchange = (c->world > 1 || c->opt.vis_exchange == 2) && c->comm.comm && c->opt.vis_exchange != 1;
     if (exchange) {
         // when the slot buffers do not fit beside the F shard every rank traces for itself.  Decided from rank-independent
         // numbers and the card's TOTAL memory, so that all ranks of a homogeneous node decide alike.
@@ -621,7 +722,7 @@ int dr_formfactors_assemble(dr_context* c, const float* uv, int K, float eps, in
     if (!all_ok) return fail(DR_ERR_COMM, "another rank could not set up the assembly; nothing was traced");
     // the first launch, then a second go / no-go: a rank whose kernel failed to launch or faulted must not leave the others
     // waiting in the all-to-all (it still takes part in the agreement -- a failed launch leaves the stream usable)
-    rc = (c->fault_assemble_rank == c->rank) ? fail(DR_ERR_DEVICE, "injected failure of the first assembly launch (DR_FAULT_ASSEMBLE_RANK)")
+    rc = (c->opt.fault_assemble_rank == c->rank) ? fail(DR_ERR_DEVICE, "injected failure of the first assembly launch (dr_options::fault_assemble_rank)")
                                               : assemble_launch(c, K, eps, rule, 1, 1);
     if (rc == DR_OK) rc = assemble_complete(c, 1);
     const std::string first_err = rc ? g_err : std::string();
@@ -736,8 +837,8 @@ int dr_solver_init(dr_context* c, int S, const float* E, const float* M, int n_m
     for (int i = 0; i < c->N; i++)
         if (mat_of_patch[i] < 0 || mat_of_patch[i] >= n_mat)
             return fail(DR_ERR_INVALID, "material index %d of patch %d out of range [0,%d)", mat_of_patch[i], i, n_mat);
-    // DR_NO_COMM=1: time one rank's shard alone (its residual chunks of other ranks stay at E)
-    if (c->world > 1 && !c->comm.comm && !c->manual_exchange && !getenv("DR_NO_COMM"))
+    // dr_options::no_comm: time one rank's shard alone (its residual chunks of other ranks stay at E)
+    if (c->world > 1 && !c->comm.comm && !c->manual_exchange && !c->opt.no_comm)
         return fail(DR_ERR_STATE, "world=%d but dr_comm_init has not been called", c->world);
     HIPCHK(hipStreamSynchronize(c->stream));
     free_solver(c);
@@ -750,12 +851,20 @@ int dr_solver_init(dr_context* c, int S, const float* E, const float* M, int n_m
     HIPCHK(hipMalloc(&c->d_R[1], sizeof(float) * full));
     HIPCHK(hipMalloc(&c->d_B, sizeof(float) * (size_t)S * c->rpr));
     HIPCHK(hipMalloc(&c->d_mat, sizeof(int) * (size_t)c->rpr));
-    c->ksplit = sweep_ksplit(c->nrows, S, (int)c->ldF);
+    const SweepTuning tune = sweep_tuning(c->opt);
+    c->ksplit = sweep_ksplit(c->nrows, S, (int)c->ldF, tune);
     if (c->ksplit > 1) HIPCHK(hipMalloc(&c->d_Gpart, sizeof(float) * (size_t)c->ksplit * std::max(c->nrows, 1) * S));
-    const size_t row_blocks = (size_t)std::max(sweep_row_blocks(c->nrows, S), 1);
+    const size_t row_blocks = (size_t)std::max(sweep_row_blocks(c->nrows, S, tune), 1);
     HIPCHK(hipMalloc(&c->d_tickets, sizeof(unsigned) * (1 + row_blocks)));
     HIPCHK(hipMalloc(&c->d_blk_sums, sizeof(double) * row_blocks * S));
     HIPCHK(hipMalloc(&c->d_ctl, sizeof(int) * 4));
+    // (written by the other devices of an in-pass-exchanging group: fine-grained where the runtime offers it)
+    if (hipExtMallocWithFlags((void**)&c->d_seq, sizeof(unsigned) * MAX_GROUP, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(hipMalloc(&c->d_seq, sizeof(unsigned) * MAX_GROUP));
+    }
+    HIPCHK(hipMemsetAsync(c->d_seq, 0, sizeof(unsigned) * MAX_GROUP, c->stream));
+    c->pass_seq = 0;
     HIPCHK(hipMemsetAsync(c->d_tickets, 0, sizeof(unsigned) * (1 + row_blocks), c->stream));
     HIPCHK(hipMemsetAsync(c->d_ctl, 0, sizeof(int) * 4, c->stream));
     HIPCHK(hipMalloc(&c->d_stage, sizeof(float) * std::max((size_t)c->N * S, (size_t)3 * DR_MAX_BINS)));
@@ -780,6 +889,8 @@ int dr_solver_reset(dr_context* c) {
     if (!c->have_solver) return fail(DR_ERR_STATE, "dr_solver_init has not been called");
     const size_t full = (size_t)c->world * c->cstride;
     c->cur = 0;
+    HIPCHK(hipMemsetAsync(c->d_seq, 0, sizeof(unsigned) * MAX_GROUP, c->stream));      // (a group resets all its ranks behind a sync)
+    c->pass_seq = 0;
     HIPCHK(hipMemcpyAsync(c->d_R[0], c->d_E, sizeof(float) * full, hipMemcpyDeviceToDevice, c->stream));
     c->tails_valid = true;            // d_E carries its sums (dr_solver_init)
     HIPCHK(hipMemcpyAsync(c->d_B, c->d_E + (size_t)c->rank * c->cstride, sizeof(float) * (size_t)c->S * c->rpr,
@@ -847,7 +958,7 @@ int dr_solver_converge(dr_context* c, float threshold, int per_bin, int max_iter
         }
         HIPCHK(hipMemcpyAsync(ctl, c->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (getenv("DR_DEBUG_CONV")) fprintf(stderr, "[daisyriot] converge: queued %d, passes done %d, converged flag %d\n", queued, ctl[0], ctl[1]);
+        if (c->opt.debug_converge) fprintf(stderr, "[daisyriot] converge: queued %d, passes done %d, converged flag %d\n", queued, ctl[0], ctl[1]);
         if (ctl[1] != 0 || ctl[0] < queued || queued >= max_iters) break;
     }
     // passes after the converged one did nothing: the current residual is the one the last REAL pass wrote
@@ -1015,7 +1126,11 @@ int dr_debug_sah_topology(int N, const float* boxes, int32_t* order, int32_t* le
     if (N < 1 || !boxes || !order || !parent || (N > 1 && (!left || !right || !first || !last)))
         return fail(DR_ERR_INVALID, "dr_debug_sah_topology: N >= 1 and every array");
     SahTopology T;
-    sah_topology_from_boxes(N, boxes, T);
+    dr_options o;
+    options_from_env(&o);
+    TreeOptions topt;
+    topt.sah = true; topt.sah_on_host = true; topt.sah_bins = o.sah_bins; topt.sah_dilate = o.sah_dilate; topt.sah_host_threads = o.sah_host_threads;
+    sah_topology_from_boxes(N, boxes, T, topt);
     std::memcpy(order, T.order.data(), sizeof(int) * (size_t)N);
     if (N > 1) {
         std::memcpy(left, T.left.data(), sizeof(int) * (size_t)(N - 1)); std::memcpy(right, T.right.data(), sizeof(int) * (size_t)(N - 1));
@@ -1052,6 +1167,8 @@ int dr_get_info(dr_context* c, dr_info* o) {
     o->last_assemble_ms = c->last_assemble_ms; o->last_bvh_ms = c->last_bvh_ms; o->pairs_traced = c->pairs_traced;
     o->sweep_launches = c->sweep_launches; o->sweep_ms_total = c->sweep_ms_total;
     o->blocks_nonzero = c->mask_valid ? c->blocks_nonzero : 0; o->blocks_total = c->mask_valid ? c->blocks_total : 0;
+    o->tree_used = c->tree_used; o->tree_on_host = c->tree_on_host; o->tree_depth = c->tree_depth; o->walk_used = c->walk_used;
+    o->sweep_ksplit = c->have_solver ? c->ksplit : 0;
     return DR_OK;
 }
 
@@ -1089,14 +1206,48 @@ int dr_comm_info(dr_context* c, int* rccl_rank, int* rccl_world) {
 struct dr_group {
     std::vector<dr_context*> ctx;
     std::vector<int> devices;
-    bool rccl = false;                  // residual / ray-count exchange through RCCL (distinct devices); else peer copies
+    bool rccl = false;                  // a communicator per rank exists (distinct devices): ray counts always travel through it
+    bool rccl_pass = false;             // ... and so does the residual after a pass; else peer copies, or
+    bool inpass = false;                // the pass stores its chunk into every device's buffer itself (dr_options::group_exchange = INPASS)
     std::vector<hipEvent_t> ev_done;    // per rank: its pass has written its chunk (peer-copy exchange)
 };
+
+// how the residual travels after a pass: decided from the options at creation and again by dr_group_set_options
+static int group_pick_exchange(dr_group* g, int ex) {
+    const int n = (int)g->ctx.size();
+    if (ex == DR_GROUP_EXCHANGE_RCCL && !g->rccl && n > 1)
+        return fail(DR_ERR_INVALID, "group_exchange = RCCL needs distinct devices (a communicator per rank)");
+    if (ex == DR_GROUP_EXCHANGE_INPASS && n > MAX_GROUP) return fail(DR_ERR_INVALID, "in-pass exchange supports up to %d devices", MAX_GROUP);
+    if (ex == DR_GROUP_EXCHANGE_INPASS) {
+        // ranks that share a device (a rehearsal) wait for each other ON the device: their streams must not share a hardware
+        // queue, or a rank's gate kernel would sit in front of the very pass it waits for (it would time out, not hang) --
+        // the runtime spreads a device's streams over 4 queues
+        int most = 0;
+        for (int d : g->devices) { int same = 0; for (int e : g->devices) same += e == d; most = std::max(most, same); }
+        if (most > 4) return fail(DR_ERR_INVALID, "in-pass exchange: at most 4 ranks of a group may share one device (%d do)", most);
+    }
+    g->inpass = n > 1 && ex == DR_GROUP_EXCHANGE_INPASS;
+    g->rccl_pass = g->rccl && !g->inpass && ex != DR_GROUP_EXCHANGE_P2P;
+    for (dr_context* c : g->ctx) {
+        c->manual_exchange = !g->rccl_pass;             // no collective inside sweep_once
+        c->inpass_peers.clear();
+        if (g->inpass) c->inpass_peers = g->ctx;
+    }
+    return DR_OK;
+}
 
 #define GRP(g) do { if (!(g) || (g)->ctx.empty()) return fail(DR_ERR_INVALID, "null group"); } while (0)
 
 static int group_sync(dr_group* g) {
     for (dr_context* c : g->ctx) { int rc = dr_synchronize(c); if (rc) return rc; }
+    if (g->inpass)
+        for (dr_context* c : g->ctx) {
+            if (!c->d_ctl) continue;
+            int err = 0;
+            HIPCHK(hipSetDevice(c->device));
+            HIPCHK(hipMemcpy(&err, c->d_ctl + 3, sizeof(int), hipMemcpyDeviceToHost));
+            if (err) return fail(DR_ERR_COMM, "in-pass exchange: rank %d waited in vain for a peer's pass (gate timed out)", c->rank);
+        }
     return DR_OK;
 }
 
@@ -1123,26 +1274,28 @@ int dr_group_create(const int* device_ids, int n, dr_group** out) {
         c->rank = r; c->world = n;
     }
     // Distinct devices: RCCL (ncclCommInitAll), as between processes.  The same device several times (a one-GPU
-    // rehearsal of the group) cannot be an RCCL communicator: peer copies then -- also selectable with DR_GROUP_EXCHANGE=p2p.
-    const char* ex = getenv("DR_GROUP_EXCHANGE");
-    g->rccl = n > 1 && distinct && !(ex && !strcmp(ex, "p2p"));
+    // rehearsal of the group) cannot be an RCCL communicator: peer copies then -- also selectable with the options.
+    g->rccl = n > 1 && distinct;
     if (g->rccl) {
         std::vector<Comm> cs;
         std::string e = comm_init_all(cs, device_ids, n);
         if (!e.empty()) { dr_group_destroy(g); return fail(DR_ERR_COMM, "%s", e.c_str()); }
-        for (int r = 0; r < n; r++) g->ctx[r]->comm = cs[r];
-    } else {
         for (int r = 0; r < n; r++) {
-            g->ctx[r]->manual_exchange = true;
+            g->ctx[r]->comm = cs[r];
             hipSetDevice(device_ids[r]);
-            hipEvent_t ev;
-            hipError_t he = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-            if (he != hipSuccess) { dr_group_destroy(g); return fail(DR_ERR_DEVICE, "hipEventCreate: %s", hipGetErrorString(he)); }
-            g->ev_done.push_back(ev);
-            for (int q = 0; q < n; q++)        // direct xGMI copies where the devices allow it (an error here only means staged copies)
-                if (device_ids[q] != device_ids[r]) { (void)hipDeviceEnablePeerAccess(device_ids[q], 0); (void)hipGetLastError(); }
+            if (hipMalloc(&g->ctx[r]->d_agree, sizeof(int) * (size_t)n) != hipSuccess) { dr_group_destroy(g); return fail(DR_ERR_NOMEM, "hipMalloc"); }
         }
     }
+    for (int r = 0; r < n; r++) {
+        hipSetDevice(device_ids[r]);
+        hipEvent_t ev;
+        hipError_t he = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (he != hipSuccess) { dr_group_destroy(g); return fail(DR_ERR_DEVICE, "hipEventCreate: %s", hipGetErrorString(he)); }
+        g->ev_done.push_back(ev);
+        for (int q = 0; q < n; q++)        // direct xGMI copies / stores where the devices allow it (an error here only means staged copies)
+            if (device_ids[q] != device_ids[r]) { (void)hipDeviceEnablePeerAccess(device_ids[q], 0); (void)hipGetLastError(); }
+    }
+    { int rc = group_pick_exchange(g, g->ctx[0]->opt.group_exchange); if (rc) { dr_group_destroy(g); return rc; } }
     *out = g;
     return DR_OK;
 }
@@ -1150,8 +1303,18 @@ int dr_group_create(const int* device_ids, int n, dr_group** out) {
 int dr_group_info(dr_group* g, int* n, int* uses_rccl) {
     GRP(g);
     if (n) *n = (int)g->ctx.size();
-    if (uses_rccl) *uses_rccl = g->rccl ? 1 : 0;
+    if (uses_rccl) *uses_rccl = g->rccl_pass ? 1 : 0;
     return DR_OK;
+}
+
+int dr_group_set_options(dr_group* g, const dr_options* o) {
+    GRP(g);
+    int rc = check_options(o);
+    if (rc) return rc;
+    rc = group_sync(g);
+    if (rc) return rc;
+    for (dr_context* c : g->ctx) { rc = dr_set_options(c, o); if (rc) return rc; }
+    return group_pick_exchange(g, o->group_exchange);
 }
 
 int dr_group_context(dr_group* g, int rank, dr_context** out) {
@@ -1177,7 +1340,7 @@ int dr_group_set_mesh(dr_group* g, const float* vertices, int V, const float* no
 int dr_group_assemble(dr_group* g, const float* uv, int K, float eps, int rule, int keep_vis) {
     GRP(g);
     const int n = (int)g->ctx.size();
-    bool exchange = n > 1 && !getenv("DR_NO_VIS_EXCHANGE");
+    bool exchange = n > 1 && g->ctx[0]->opt.vis_exchange != 1;
     if (exchange) {
         dr_context* c0 = g->ctx[0];
         HIPCHK(hipSetDevice(c0->device));
@@ -1236,7 +1399,13 @@ int dr_group_solver_reset(dr_group* g) {
 // one pass on every device, then the exchange of the new residual chunks; nothing waits on the host
 static int group_pass(dr_group* g, int conv_mode, float thr) {
     const int n = (int)g->ctx.size();
-    if (g->rccl) {
+    if (g->inpass) {
+        // every pass stores its chunk into all devices' buffers and waits (on the device) for the others' previous pass:
+        // one gate + one pass kernel per rank and pass, nothing else
+        for (int r = 0; r < n; r++) { int rc = sweep_once(g->ctx[r], conv_mode, thr); if (rc) return rc; }
+        return DR_OK;
+    }
+    if (g->rccl_pass) {
         std::string e = comm_group_start();
         if (!e.empty()) return fail(DR_ERR_COMM, "%s", e.c_str());
         int rc = DR_OK;

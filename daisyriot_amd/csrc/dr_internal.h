@@ -49,18 +49,17 @@ constexpr int BVH_END = 0x7ffffff8;
 struct BvhPair { BvhNode c[2]; };       // 64 B: one s_load_dwordx16
 constexpr int PAIR_STACK = 64;
 
-// Per-patch PATH RECORDS.  Every ray of a pair (lo, hi) starts on patch lo and ends on patch hi, so it is inside every
-// ancestor of the two patches' leaves: testing those nodes (a quarter of a walk from the root) tells nothing.  What a
-// walk does need are the SIBLINGS hanging off the two root-to-leaf paths -- together with the two leaves they cover the
-// whole tree.  They are the same for every pair the patch takes part in, so the build writes them out once per patch:
-// PATH_RECS records in root-to-leaf order, record d-1 = the sibling of the path's node at depth d, a copy of its box
-// with where to go on a hit: {c, h, start, end} -- an internal sibling's subtree is the node range [start, end) past its
-// own (already tested) node; a leaf sibling has end = -1 and start = its leaf code.  PathHdr: depth of the patch's leaf
-// (-1: deeper than PATH_RECS, such patches are walked from the root), the path's turns (bit d-1 set: right child at
-// depth d), the leaf code of the patch's own leaf.  The pair's walk streams the records (addresses known up front: no
-// pointer chasing), and only enters the tree below a sibling its rays touch.
-constexpr int PATH_RECS = 32;
-struct PathHdr { int depth; unsigned turns; int leaf; int pad; };
+// Per-patch PATH RECORDS (k_paths, stream_path_records in geom_kernels.hip).  Every ray of a pair (lo, hi) starts on patch lo
+// and ends on patch hi, so it is inside every ancestor of the two patches' leaves: testing those nodes (a quarter of a walk
+// from the root) tells nothing.  What a walk does need are the SIBLINGS hanging off the two root-to-leaf paths -- together with
+// the two leaves they cover the whole tree.  They are the same for every pair the patch takes part in, so the build writes them
+// out once per patch: PATH_RECS records in root-to-leaf order, record d-1 = the sibling of the path's node at depth d: its box
+// as lower / upper corner (c[] = lo, h[] = hi, as in bvh_lh) and, in `skip`, its ITEM for the pair walk (BvhPair below).
+// PathHdr: depth of the patch's leaf (-1: deeper than PATH_RECS, such patches are walked from the root), the leaf's item, the
+// path's turns (bit d-1 set: right child at depth d).  The pair's walk streams the records (addresses known up front: no
+// pointer chasing) and pushes the items of the siblings its rays touch onto the pair walk's stack.
+constexpr int PATH_RECS = 40;
+struct PathHdr { int depth; int leaf; unsigned turns_lo, turns_hi; };
 
 constexpr int LEAF_MAX = 2;     // subtrees of up to this many triangles are collapsed into one leaf
                                 // (a leaf is fetched whole: LEAF_MAX x 16 SGPRs)
@@ -86,7 +85,7 @@ struct TileParams {
     const BvhNode* bvh_lh;      // the same nodes with c[] = lower, h[] = upper corner (sign-specialised node test); null: not used
     const BvhPair* pairs;       // sibling-pair form of the tree (BvhPair), centre / half-extent; null: the threaded form is walked
     const BvhPair* pairs_lh;    // ... lower / upper corner
-    const BvhNode* path_rec;    // [N][PATH_RECS] path records (see PathHdr); null: every walk starts at the root
+    const BvhNode* path_rec;    // [N][PATH_RECS] (+ 1 record the stream's prefetch may touch) path records (see PathHdr); null: every walk starts at the root
     const PathHdr* path_hdr;    // [N]
     const float* uv;          // K x 2
     unsigned long long* pairs_traced;   // [0] pairs traced, [1] BVH nodes visited, [2] leaves tested (wave level)
@@ -104,16 +103,7 @@ struct TileParams {
     int vx_mode, vx_rank, vx_tiles_per_rank;
     unsigned char* vsend;               // [world][tiles_per_rank][tiles_per_rank][64*64] ray counts, row = tile of the min index
     const unsigned char* vrecv;         // same shape; block B = what rank B traced for this rank
-    // Tile-pair shaft culling (build_shaft_list in geom_kernels.hip): once per workgroup the BVH is cut down to a
-    // short list of node ranges that can meet the hull of the two tiles' boxes; every pair's walk runs over that
-    // list instead of starting at the root.  shaft = 0 switches it off (every walk starts at the root).
-    int shaft;
-    int shaft_min_bytes;      // subtrees up to this many bytes of nodes are listed whole, never split further
     float ts_max;             // cap of a ray's 1/length scale in the walk's node tests: 1e19 / max|coordinate| (keeps org * iv finite)
-    float shaft_pad_ray;      // growth of a tile's box the rays' end points are checked against
-    float shaft_pad_node;     // growth of a tile's box the shaft is built from (>= pad_ray + the node test's error)
-    float shaft_tol;          // max |coordinate| + diagonal: scale of the rounding tolerance of the plane tests
-    float shaft_near_shrink;  // a node is 'near' a tile when it meets the tile's box shrunk by this fraction of its extent per side
 };
 
 // Which rank traces the tile pair {a, b} whose tiles lie in two different ranks' rows (tiles_per_rank tiles of 64 rows
@@ -124,6 +114,16 @@ __host__ __device__ inline int vx_tracer_rank(int a, int b, int tiles_per_rank) 
     const int lo = ra < rb ? ra : rb, hi = ra < rb ? rb : ra;
     return (((a + b) & 1) == 0) ? lo : hi;
 }
+
+// how a light pass is cut up (dr_options::sweep_*; none of it changes a result bit)
+struct SweepTuning {
+    int rows_per_wave = 0;   // k_sweep: 8 (4 above 8 bins: the accumulators are RR*S registers); 4 forces 4 below too; 0 auto
+    int mfma = 1;            // k_sweep_mfma above 8 bins
+    int ksplit = 0;          // column ranges per row block, 0 = by the shard's size (sweep_ksplit)
+    int skew = -1;           // per-block start-tile multiplier, -1 = by the residual's size
+    int taper = -1;          // shares of the column ranges, -1 = n, n-1, .., 1
+    int fenced = 0;          // hand-offs between the blocks of a pass through release / acquire fences instead of write-through stores
+};
 
 struct SweepParams {
     int N;            // patches (columns with data)
@@ -161,6 +161,16 @@ struct SweepParams {
     // bit is clear are not read (null = read everything).  mask_words = 32-bit words per row block.
     const unsigned* tile_mask;
     int mask_words;
+    SweepTuning tune;
+    // in-pass exchange of a one-process group (dr_options::group_exchange = INPASS): the new residual chunk (and its tail) is
+    // also stored into every other device's residual buffer, peer-mapped; peers[r] = device r's Rout (null: none / this rank)
+    float* peers[16];
+    int n_peers;
+    // ... and when the whole pass is done (last row block, after a system-scope fence) its number `seq` goes into slot `rank` of
+    // every device's sequence array peer_seq[r] -- the next pass on device r starts behind a one-thread gate kernel that waits
+    // until all world slots of ITS array show the previous pass (launch_wait_peers): no collective, no host round trip
+    unsigned* peer_seq[16];
+    unsigned seq;
 };
 
 // launchers implemented in the .hip files
@@ -172,18 +182,27 @@ struct SahTopology {
     int N = -1;
     std::vector<int> order, left, right, first, last, parent;
 };
+// what dr_scene_set_mesh builds (dr_options, resolved): sah = the binned-SAH topology instead of the Morton tree
+struct TreeOptions {
+    bool sah = false, sah_on_host = false;
+    int morton_key = 0, sah_bins = 32, sah_host_threads = 0;
+    float sah_dilate = 0.5f;
+};
 hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float scene_lo[3],
                       const float scene_hi[3], float node_pad, BvhNode* nodes /* room for 2N */,
                       BvhNode* nodes_lh /* the same in lower / upper corner form */,
                       TriRec* tri_sorted /* N + LEAF_MAX */, int* n_nodes_out,
                       BvhNode* path_rec /* N * PATH_RECS */, PathHdr* path_hdr /* N */,
-                      SahTopology* shared = nullptr /* N == this mesh's: use it; else fill it */,
+                      const TreeOptions& topt, SahTopology* shared = nullptr /* host SAH: N == this mesh's: use it; else fill it */,
                       BvhPair* pairs = nullptr /* room for max(N - 1, 1): the sibling-pair form, centre / half-extent */,
                       BvhPair* pairs_lh = nullptr /* lower / upper corner */, int* depth_out = nullptr /* depth of the written tree */);
-void sah_topology_from_boxes(int N, const float* boxes /* N x {lo[3], hi[3]} */, SahTopology& out);
+void sah_topology_from_boxes(int N, const float* boxes /* N x {lo[3], hi[3]} */, SahTopology& out, const TreeOptions& topt);
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p);
 hipError_t launch_sweep(hipStream_t st, const SweepParams& p);
-int sweep_ksplit(int nrows, int S, int total_cols);
+constexpr int MAX_GROUP = 16;   // devices of one in-pass-exchanging group (SweepParams::peers)
+// the gate in front of a pass of an in-pass-exchanging group: returns when seq_local[0 .. world) >= want (or after ~5 s: err[0] = 1)
+hipError_t launch_wait_peers(hipStream_t st, const unsigned* seq_local, int world, unsigned want, int* err);
+int sweep_ksplit(int nrows, int S, int total_cols, const SweepTuning& t);
 hipError_t launch_patch_colors(hipStream_t st, const float* B, int nrows, int rpr, int S, int mode, const float* xyz,
                                float* rgb);
 hipError_t launch_vertex_colors(hipStream_t st, const float* rgb, int V, const int* off, const int* adj, float* out);
@@ -191,7 +210,7 @@ hipError_t launch_vertex_colors(hipStream_t st, const float* rgb, int V, const i
 hipError_t launch_tile_mask(hipStream_t st, const float* F, int nrows, size_t ldF, unsigned* mask, int mask_words);
 // per-bin sums of every chunk of R into the chunk's own tail (after a reset; passes maintain them themselves)
 hipError_t launch_chunk_sums(hipStream_t st, float* R, int world, int S, int rpr, size_t cstride);
-int sweep_row_blocks(int nrows, int S);
+int sweep_row_blocks(int nrows, int S, const SweepTuning& t);
 // layout conversion between the ABI's patch-major N x S and the device's bin-major chunks
 hipError_t launch_scatter_rows(hipStream_t st, const float* src_NxS, int N, int S, int rpr, size_t cstride,
                                float* dst_chunks /* [world][cstride] */);

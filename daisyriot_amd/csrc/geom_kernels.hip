@@ -246,7 +246,8 @@ __global__ void k_emit(int N, const int* __restrict__ left, const int* __restric
                        const float* __restrict__ box, const int* __restrict__ esize, float node_pad,
                        const TriRec* __restrict__ tri_sorted, BvhNode* __restrict__ nodes, BvhNode* __restrict__ nodes_lh,
                        int* __restrict__ pre /* 2N-1, preset to -1: pre-order index of every node that is written */,
-                       BvhPair* __restrict__ pairs, BvhPair* __restrict__ pairs_lh, int* __restrict__ depth_max) {
+                       BvhPair* __restrict__ pairs, BvhPair* __restrict__ pairs_lh, int* __restrict__ depth_max,
+                       int* __restrict__ items /* 2N-1: the pair walk's item of every written node (k_paths) */) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= 2 * N - 1) return;
     const bool internal = id < N - 1;
@@ -301,6 +302,7 @@ __global__ void k_emit(int N, const int* __restrict__ left, const int* __restric
     // The sibling-pair form of the same tree (BvhPair, dr_internal.h): this node's box and "item" go into its PARENT's record.
     if (pairs != nullptr) {
         const int item = (cnt <= LEAF_MAX) ? (int)(0x80000000u | (unsigned)nd.tri) : iidx * (int)sizeof(BvhPair);
+        items[id] = item;
         if (depth > 0) {
             BvhNode a = nd, b = lh;
             a.skip = item; a.tri = 0; b.skip = item; b.tri = 0;
@@ -322,18 +324,18 @@ __global__ void k_emit(int N, const int* __restrict__ left, const int* __restric
 }
 
 // The path records of every patch (PathHdr, dr_internal.h): climb from the patch's leaf to the root, copying the sibling
-// of every node on the way.
+// of every node on the way -- its box as lower / upper corner (the sign-specialised node test) and its item for the pair walk.
 __global__ void k_paths(int N, const int* __restrict__ pos, const int* __restrict__ left, const int* __restrict__ right,
-                        const int* __restrict__ parent, const int* __restrict__ pre, const BvhNode* __restrict__ nodes,
-                        BvhNode* __restrict__ rec, PathHdr* __restrict__ hdr) {
+                        const int* __restrict__ parent, const int* __restrict__ pre, const int* __restrict__ items,
+                        const BvhNode* __restrict__ nodes, const BvhNode* __restrict__ nodes_lh, BvhNode* __restrict__ rec, PathHdr* __restrict__ hdr) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
     int id = N - 1 + pos[p];
     if (N > 1)
         while (pre[id] < 0) id = parent[id];          // inside a collapsed subtree: up to the leaf that was written for it
     PathHdr h;
-    h.leaf = nodes[N > 1 ? pre[id] : 0].tri;
-    h.turns = 0u; h.pad = 0;
+    h.leaf = (int)(0x80000000u | (unsigned)nodes[N > 1 ? pre[id] : 0].tri);
+    h.turns_lo = 0u; h.turns_hi = 0u;
     int D = 0;
     if (N > 1)
         for (int c = id; c != 0; c = parent[c]) D++;
@@ -344,10 +346,10 @@ __global__ void k_paths(int N, const int* __restrict__ pos, const int* __restric
         const int q = parent[c];
         const bool is_right = right[q] == c;
         const int sib = is_right ? left[q] : right[q];
-        if (is_right) h.turns |= 1u << (d - 1);
-        BvhNode nd = nodes[pre[sib]];
-        if (nd.tri >= 0) { nd.skip = nd.tri; nd.tri = -1; }                            // a leaf: start = its leaf code, end = -1
-        else { const int end = nd.skip; nd.skip = (pre[sib] + 1) * (int)sizeof(BvhNode); nd.tri = end; }   // below the sibling's own node
+        if (is_right) { if (d - 1 < 32) h.turns_lo |= 1u << (d - 1); else h.turns_hi |= 1u << (d - 33); }
+        BvhNode nd = nodes_lh[pre[sib]];
+        nd.skip = items[sib];
+        nd.tri = 0;
         rec[(size_t)p * PATH_RECS + (d - 1)] = nd;
         c = q;
     }
@@ -365,7 +367,314 @@ __global__ void k_pad_tris(int N, TriRec* __restrict__ tri_sorted) {
 }
 
 // ---------------------------------------------------------------------------------------
-// DR_BVH=sah: the tree's TOPOLOGY from a top-down binned surface-area heuristic on the host (one thread: a data-dependent
+// The SAH topology ON THE DEVICE (dr_options::tree = SAH, the default from 6 144 patches up): the same top-down binned build as
+// sah_hierarchy_host below -- 32 bins per axis over the centroids of the patches' gate boxes, cost = (area of the box grown by
+// half a mean patch diagonal) x count, cuts that leave less than 1/32 on a side not admitted above 64 patches, the same float
+// expressions in the same order, ties to the first (axis, bin) -- level by level: one workgroup per open node and level
+// (k_sah_level, grid-stride over the level's node queue), each of which finds its node's centroid bounds, bins its patches in
+// LDS (integer atomics on order-preserving keys of the floats), evaluates the 3 x 31 planes, partitions its stretch of the
+// leaf order into the other of two order buffers and queues its children; nodes of one or two patches are closed on the spot.
+// No admissible plane (every cut lopsided, or all centroids in one bin): the exact median along the longest axis by a radix
+// select on the centroids' keys (the host uses nth_element), which keeps the depth logarithmic on any input.  Node ids, ranges
+// and arrays are the host builder's (and k_hierarchy's): a node over n leaves owns the interior ids [id, id + n - 1).
+// Any tree gives bit-identical results; this one is the host's up to the order inside a leaf pair and tie cases.
+// ---------------------------------------------------------------------------------------
+struct SahJob { int b, e, id; };
+constexpr int SAH_NT = 256;
+constexpr int SAH_NBMAX = 128;
+
+__device__ __forceinline__ int f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+// centroids of the gate boxes (the host's expression) and the deterministic mean of the boxes' diagonals (one block)
+__global__ __launch_bounds__(1024) void k_sah_prepare(int N, const TriRec* __restrict__ tri, float* __restrict__ cen, double* __restrict__ diag_mean,
+                                                      int* __restrict__ order) {
+    __shared__ double sh[1024];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < N; i += 1024) {
+        const TriRec T = tri[i];
+        double q = 0.0;
+        for (int x = 0; x < 3; x++) {
+            cen[3 * (size_t)i + x] = 0.5f * T.lo[x] + 0.5f * T.hi[x];
+            const double d = (double)T.hi[x] - (double)T.lo[x];
+            q += d * d;
+        }
+        a += sqrt(q);
+        order[i] = i;
+    }
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) diag_mean[0] = sh[0] / (double)N;
+}
+
+__device__ __forceinline__ float sah_area(const float lo[3], const float hi[3], float grow) {
+    const float dx = fmaxf(hi[0] - lo[0], 0.0f) + grow, dy = fmaxf(hi[1] - lo[1], 0.0f) + grow, dz = fmaxf(hi[2] - lo[2], 0.0f) + grow;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// exclusive scan of one flag per thread over the block (SAH_NT threads); total in *tot
+__device__ __forceinline__ int block_rank(bool flag, int* sWave /* SAH_NT / 64 + 1 */, int& tot) {
+    const unsigned long long m = __ballot(flag);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sWave[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0;
+    tot = 0;
+    for (int w = 0; w < SAH_NT / 64; w++) { const int c = sWave[w]; if (w < wave) base += c; tot += c; }
+    __syncthreads();
+    return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
+__global__ __launch_bounds__(SAH_NT) void k_sah_level(int N, const TriRec* __restrict__ tri, const float* __restrict__ cen, const double* __restrict__ diag_mean,
+                                                      float dilate, int NB, const SahJob* __restrict__ qin, const int* __restrict__ n_in, SahJob* __restrict__ qout,
+                                                      int* __restrict__ n_out, const int* __restrict__ src, int* __restrict__ dst, int* __restrict__ order_out,
+                                                      int* __restrict__ left, int* __restrict__ right, int* __restrict__ first, int* __restrict__ last,
+                                                      int* __restrict__ parent) {
+    __shared__ int sCnt[3][SAH_NBMAX];
+    __shared__ int sLo[3][SAH_NBMAX][3], sHi[3][SAH_NBMAX][3];
+    __shared__ int sC[6];                      // centroid bounds as ordered keys: lo[3], hi[3]
+    __shared__ float sCost[SAH_NT];
+    __shared__ int sIdx[SAH_NT];
+    __shared__ int sWave[SAH_NT / 64 + 1];
+    __shared__ int sHist[256];
+    __shared__ int sSel[4];                    // split: mode (0 plane, 1 median, 2 halves as they lie), axis, bin / key, count on the left
+    const int tid = threadIdx.x;
+    const float grow = dilate * (float)diag_mean[0];
+    const int njobs = *n_in;
+    for (int j = blockIdx.x; j < njobs; j += gridDim.x) {
+        const SahJob J = qin[j];
+        const int b = J.b, e = J.e, n = e - b;
+        // ---- 1. bounds of the centroids
+        if (tid < 6) sC[tid] = tid < 3 ? 0x7fffffff : (int)0x80000000;
+        for (int x = tid; x < 3 * SAH_NBMAX; x += SAH_NT) {
+            (&sCnt[0][0])[x] = 0;
+            for (int d = 0; d < 3; d++) { (&sLo[0][0][0])[3 * x + d] = 0x7fffffff; (&sHi[0][0][0])[3 * x + d] = (int)0x80000000; }
+        }
+        __syncthreads();
+        {
+            int lo3[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi3[3] = { (int)0x80000000, (int)0x80000000, (int)0x80000000 };
+            for (int k = b + tid; k < e; k += SAH_NT) {
+                const int t = src[k];
+                for (int a = 0; a < 3; a++) { const int o = f2ord(cen[3 * (size_t)t + a]); lo3[a] = min(lo3[a], o); hi3[a] = max(hi3[a], o); }
+            }
+            for (int a = 0; a < 3; a++) {
+                for (int o = 32; o >= 1; o >>= 1) { lo3[a] = min(lo3[a], __shfl_xor(lo3[a], o)); hi3[a] = max(hi3[a], __shfl_xor(hi3[a], o)); }
+                if ((tid & 63) == 0) { atomicMin(&sC[a], lo3[a]); atomicMax(&sC[3 + a], hi3[a]); }
+            }
+        }
+        __syncthreads();
+        float clo[3], chi[3], scale[3];
+        bool valid[3];
+        for (int a = 0; a < 3; a++) {
+            clo[a] = ord2f(sC[a]); chi[a] = ord2f(sC[3 + a]);
+            const float ext = chi[a] - clo[a];
+            scale[a] = (float)NB / ext;
+            valid[a] = (ext > 0.0f) && isfinite(scale[a]);
+        }
+        // ---- 2. bins
+        for (int k = b + tid; k < e; k += SAH_NT) {
+            const int t = src[k];
+            const TriRec T = tri[t];
+            for (int a = 0; a < 3; a++) {
+                if (!valid[a]) continue;
+                const int q = max(0, min(NB - 1, (int)((cen[3 * (size_t)t + a] - clo[a]) * scale[a])));
+                atomicAdd(&sCnt[a][q], 1);
+                for (int d = 0; d < 3; d++) { atomicMin(&sLo[a][q][d], f2ord(T.lo[d])); atomicMax(&sHi[a][q][d], f2ord(T.hi[d])); }
+            }
+        }
+        __syncthreads();
+        // ---- 3. the planes: candidate x = a * (NB - 1) + q cuts axis a between bins q and q + 1
+        float best = INFINITY;
+        int best_x = 0x7fffffff;
+        for (int x = tid; x < 3 * (NB - 1); x += SAH_NT) {
+            const int a = x / (NB - 1), q = x % (NB - 1);
+            if (!valid[a]) continue;
+            float lo3[3] = { INFINITY, INFINITY, INFINITY }, hi3[3] = { -INFINITY, -INFINITY, -INFINITY };
+            int c = 0;
+            for (int p = 0; p <= q; p++) {
+                if (sCnt[a][p] == 0) continue;                   // (an empty bin's box is [inf, -inf]: min / max leave the others alone)
+                for (int d = 0; d < 3; d++) { lo3[d] = fminf(lo3[d], ord2f(sLo[a][p][d])); hi3[d] = fmaxf(hi3[d], ord2f(sHi[a][p][d])); }
+                c += sCnt[a][p];
+            }
+            float rlo[3] = { INFINITY, INFINITY, INFINITY }, rhi[3] = { -INFINITY, -INFINITY, -INFINITY };
+            int rc = 0;
+            for (int p = NB - 1; p > q; p--) {
+                if (sCnt[a][p] == 0) continue;
+                for (int d = 0; d < 3; d++) { rlo[d] = fminf(rlo[d], ord2f(sLo[a][p][d])); rhi[d] = fmaxf(rhi[d], ord2f(sHi[a][p][d])); }
+                rc += sCnt[a][p];
+            }
+            if (c == 0 || rc == 0) continue;
+            if (n > 64 && (long long)min(c, rc) * 32 < n) continue;       // (keeps the depth, and the build's cost, logarithmic)
+            const float cost = sah_area(lo3, hi3, grow) * (float)c + sah_area(rlo, rhi, grow) * (float)rc;
+            if (cost < best) { best = cost; best_x = x; }
+        }
+        sCost[tid] = best; sIdx[tid] = best_x;
+        __syncthreads();
+        for (int w = SAH_NT / 2; w >= 1; w >>= 1) {
+            if (tid < w) {
+                const float c2 = sCost[tid + w]; const int i2 = sIdx[tid + w];
+                if (c2 < sCost[tid] || (c2 == sCost[tid] && i2 < sIdx[tid])) { sCost[tid] = c2; sIdx[tid] = i2; }
+            }
+            __syncthreads();
+        }
+        // ---- the split: a plane; else the median along the longest axis with extent; else the halves as they lie
+        int axis = -1;
+        if (sIdx[0] != 0x7fffffff && n > 2) {
+            if (tid == 0) {
+                const int a = sIdx[0] / (NB - 1), q = sIdx[0] % (NB - 1);
+                int c = 0;
+                for (int p = 0; p <= q; p++) c += sCnt[a][p];
+                sSel[0] = 0; sSel[1] = a; sSel[2] = q; sSel[3] = c;
+            }
+        } else {
+            for (int a = 0; a < 3; a++)
+                if (chi[a] - clo[a] > 0.0f && (axis < 0 || chi[a] - clo[a] > chi[axis] - clo[axis])) axis = a;
+            if (axis < 0 || n <= 2) { if (tid == 0) { sSel[0] = 2; sSel[1] = 0; sSel[2] = 0; sSel[3] = n / 2; } }
+            else {
+                // radix select of the (n / 2)-th smallest key (0-based) along `axis`: four rounds of eight bits, most significant first
+                unsigned prefix = 0u, pmask = 0u;
+                int want = n / 2;                    // rank inside the keys that match the prefix so far
+                for (int sh = 24; sh >= 0; sh -= 8) {
+                    sHist[tid] = 0;
+                    __syncthreads();
+                    for (int k = b + tid; k < e; k += SAH_NT) {
+                        const unsigned key = (unsigned)f2ord(cen[3 * (size_t)src[k] + axis]) ^ 0x80000000u;      // unsigned order
+                        if ((key & pmask) == prefix) atomicAdd(&sHist[(key >> sh) & 255u], 1);
+                    }
+                    __syncthreads();
+                    if (tid == 0) {
+                        int acc = 0, dsel = 255;
+                        for (int d = 0; d < 256; d++) { if (acc + sHist[d] > want) { dsel = d; break; } acc += sHist[d]; }
+                        sSel[1] = dsel; sSel[2] = acc;
+                    }
+                    __syncthreads();
+                    prefix |= (unsigned)sSel[1] << sh; pmask |= 255u << sh;
+                    want -= sSel[2];
+                    __syncthreads();
+                }
+                // prefix = the median's key; `want` of the keys equal to it go left (with all smaller ones): n / 2 on the left
+                if (tid == 0) { sSel[0] = 1; sSel[1] = axis; sSel[2] = (int)prefix; sSel[3] = n / 2; }
+                sWave[SAH_NT / 64] = want;          // (every thread writes the same value)
+            }
+        }
+        __syncthreads();
+        const int mode = sSel[0], sax = sSel[1], sval = sSel[2], nl = sSel[3], nr = n - nl;
+        const int eq_quota = sWave[SAH_NT / 64];
+        const int m = b + nl;
+        __syncthreads();
+        // ---- 4. partition into the other order buffer (stretches that are final -- children of one or two patches -- also into order_out)
+        int offL = 0, offR = 0, offE = 0;
+        for (int base = b; base < e; base += SAH_NT) {
+            const int k = base + tid;
+            const bool in = k < e;
+            int t = 0;
+            bool goes_left = false, is_eq = false;
+            if (in) {
+                t = src[k];
+                if (mode == 0) goes_left = max(0, min(NB - 1, (int)((cen[3 * (size_t)t + sax] - clo[sax]) * scale[sax]))) <= sval;
+                else if (mode == 1) {
+                    const unsigned key = (unsigned)f2ord(cen[3 * (size_t)t + sax]) ^ 0x80000000u;
+                    goes_left = key < (unsigned)sval; is_eq = key == (unsigned)sval;
+                } else goes_left = (k - b) < nl;
+            }
+            if (mode == 1) {
+                int totE;
+                const int re = block_rank(is_eq, sWave, totE);
+                if (is_eq) goes_left = (offE + re) < eq_quota;
+                offE += totE;
+            }
+            int totL, totR;
+            const int rl = block_rank(in && goes_left, sWave, totL);
+            const int rr = block_rank(in && !goes_left, sWave, totR);
+            if (in) {
+                const int at = goes_left ? b + offL + rl : m + offR + rr;
+                dst[at] = t;
+                if ((goes_left ? nl : nr) <= 2) order_out[at] = t;
+            }
+            offL += totL; offR += totR;
+        }
+        // ---- 5. the node's record; its children: closed here (one or two patches) or queued
+        if (tid == 0) {
+            first[J.id] = b; last[J.id] = e - 1;
+            const int lc = nl == 1 ? N - 1 + b : J.id + 1;
+            const int rc = nr == 1 ? N - 1 + m : J.id + 1 + (nl - 1);
+            left[J.id] = lc; right[J.id] = rc; parent[lc] = J.id; parent[rc] = J.id;
+            for (int side = 0; side < 2; side++) {
+                const int cb = side ? m : b, ce = side ? e : m, cid = side ? rc : lc, cn = ce - cb;
+                if (cn == 2) {
+                    first[cid] = cb; last[cid] = cb + 1;
+                    left[cid] = N - 1 + cb; right[cid] = N - 1 + cb + 1;
+                    parent[N - 1 + cb] = cid; parent[N - 1 + cb + 1] = cid;
+                } else if (cn >= 3) {
+                    const int at = atomicAdd(n_out, 1);
+                    qout[at] = SahJob{ cb, ce, cid };
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// the queue's first job (the root, when it has three patches or more) and the trees of one and two patches
+__global__ void k_sah_seed(int N, SahJob* __restrict__ q, int* __restrict__ cnt, int* __restrict__ order_out, int* __restrict__ left, int* __restrict__ right,
+                           int* __restrict__ first, int* __restrict__ last, int* __restrict__ parent) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    parent[0] = -1;
+    cnt[0] = 0; cnt[1] = 0;
+    if (N >= 3) { q[0] = SahJob{ 0, N, 0 }; cnt[0] = 1; }
+    else {
+        for (int k = 0; k < N; k++) order_out[k] = k;
+        if (N == 2) { first[0] = 0; last[0] = 1; left[0] = 1; right[0] = 2; parent[1] = 0; parent[2] = 0; }
+    }
+}
+
+// order_out, left, right, first, last, parent: the arrays k_hierarchy writes for the Morton tree (device pointers)
+static hipError_t sah_hierarchy_device(hipStream_t st, int N, const TriRec* tri, const TreeOptions& topt, int* order_out, int* left, int* right,
+                                       int* first, int* last, int* parent) {
+    hipError_t e = hipSuccess;
+    float* cen = nullptr; double* dmean = nullptr; int* ord = nullptr; SahJob* q = nullptr; int* cnt = nullptr;
+    const size_t qcap = (size_t)N / 3 + 2;
+    const int NB = std::min(std::max(topt.sah_bins, 2), SAH_NBMAX);
+#define DR_TRY(x) do { e = (x); if (e != hipSuccess) goto done; } while (0)
+    DR_TRY(hipMalloc(&cen, sizeof(float) * 3 * (size_t)N));
+    DR_TRY(hipMalloc(&dmean, sizeof(double)));
+    DR_TRY(hipMalloc(&ord, sizeof(int) * 2 * (size_t)N));
+    DR_TRY(hipMalloc(&q, sizeof(SahJob) * 2 * qcap));
+    DR_TRY(hipMalloc(&cnt, sizeof(int) * 2));
+    hipLaunchKernelGGL(k_sah_prepare, dim3(1), dim3(1024), 0, st, N, tri, cen, dmean, ord);
+    DR_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_sah_seed, dim3(1), dim3(64), 0, st, N, q, cnt, order_out, left, right, first, last, parent);
+    DR_TRY(hipGetLastError());
+    if (N >= 3) {
+        const int grid = (int)std::min<size_t>(qcap, 4096);
+        for (int level = 0;; level++) {
+            const int in = level & 1, out = in ^ 1;
+            DR_TRY(hipMemsetAsync(cnt + out, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_sah_level, dim3(grid), dim3(SAH_NT), 0, st, N, tri, cen, dmean, topt.sah_dilate, NB, q + (size_t)in * qcap, cnt + in,
+                               q + (size_t)out * qcap, cnt + out, ord + (size_t)in * N, ord + (size_t)out * N, order_out, left, right, first, last, parent);
+            DR_TRY(hipGetLastError());
+            if ((level & 7) == 7) {           // look once per eight levels whether nodes are still open
+                int open = 0;
+                DR_TRY(hipMemcpyAsync(&open, cnt + out, sizeof(int), hipMemcpyDeviceToHost, st));
+                DR_TRY(hipStreamSynchronize(st));
+                if (open == 0) break;
+                if (level > 4096) { e = hipErrorUnknown; goto done; }     // (cannot happen: every split leaves both sides non-empty)
+            }
+        }
+    }
+    DR_TRY(hipStreamSynchronize(st));
+#undef DR_TRY
+done:
+    (void)hipFree(cen); (void)hipFree(dmean); (void)hipFree(ord); (void)hipFree(q); (void)hipFree(cnt);
+    return e;
+}
+
+// ---------------------------------------------------------------------------------------
+// The REFERENCE builder of the same topology on the host (dr_options::sah_on_host; tests compare the two): a top-down binned surface-area heuristic (one thread: a data-dependent
 // recursion over at most a few hundred thousand boxes, tens of milliseconds), in the arrays k_hierarchy would have written
 // (internal nodes 0 .. N-2 with 0 the root, leaf k = N-1+k for position k of the leaf order); bounds, collapsing into leaves,
 // the pre-order threaded layout and the path records stay on the device (k_refit, k_emit, k_paths).  Any binary tree over
@@ -374,10 +683,9 @@ __global__ void k_pad_tris(int N, TriRec* __restrict__ tri_sorted) {
 // ray through the interior enters), this one's are thin sheets.
 // ---------------------------------------------------------------------------------------
 static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, std::vector<int>& left, std::vector<int>& right,
-                               std::vector<int>& first, std::vector<int>& last, std::vector<int>& parent) {
+                               std::vector<int>& first, std::vector<int>& last, std::vector<int>& parent, const TreeOptions& topt) {
     constexpr int NBMAX = 128;
-    const char* nbe = getenv("DR_SAH_BINS");
-    const int NB = nbe ? std::min(std::max(atoi(nbe), 2), NBMAX) : 32;
+    const int NB = std::min(std::max(topt.sah_bins, 2), NBMAX);
     order.resize(N); for (int i = 0; i < N; i++) order[i] = i;
     left.assign(N > 1 ? N - 1 : 1, 0); right = left; first = left; last = left;
     parent.assign(2 * (size_t)N - 1, -1);
@@ -388,8 +696,7 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
     // that goes with the area of the box grown by the bundle's radius -- DR_SAH_DILATE x the mean patch-box diagonal
     double dsum = 0.0;
     for (int i = 0; i < N; i++) { double q = 0; for (int a = 0; a < 3; a++) { const double d = (double)T[i].hi[a] - T[i].lo[a]; q += d * d; } dsum += std::sqrt(q); }
-    const char* dle = getenv("DR_SAH_DILATE");
-    const float grow = (dle ? (float)atof(dle) : 0.5f) * (float)(dsum / N);      // (0 -> 0.5: 78.7 -> 77.6 node visits per pair)
+    const float grow = topt.sah_dilate * (float)(dsum / N);      // (0 -> 0.5: 78.7 -> 77.6 node visits per pair)
     auto area = [grow](const float* lo, const float* hi) {
         const float dx = std::max(hi[0] - lo[0], 0.0f) + grow, dy = std::max(hi[1] - lo[1], 0.0f) + grow, dz = std::max(hi[2] - lo[2], 0.0f) + grow;
         return dx * dy + dy * dz + dz * dx;
@@ -410,13 +717,15 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
             float best = INFINITY; int best_axis = -1, best_bin = 0;
             for (int a = 0; a < 3; a++) {
                 const float ext = chi[a] - clo[a];
-                if (!(ext > 0.0f)) continue;
                 const float scale = (float)NB / ext;
+                // a degenerate axis: no extent, or one so small (denormal) that NB / ext overflows -- (cen - clo) * inf would be
+                // 0 * inf = NaN for the lowest centroid and its conversion to int undefined
+                if (!(ext > 0.0f) || !std::isfinite(scale)) continue;
                 int cnt[NBMAX]; float blo[NBMAX][3], bhi[NBMAX][3];
                 for (int q = 0; q < NB; q++) { cnt[q] = 0; for (int d = 0; d < 3; d++) { blo[q][d] = INFINITY; bhi[q][d] = -INFINITY; } }
                 for (int k = j.b; k < j.e; k++) {
                     const int t = order[k];
-                    const int q = std::min(NB - 1, (int)((cen[3 * (size_t)t + a] - clo[a]) * scale));
+                    const int q = std::max(0, std::min(NB - 1, (int)((cen[3 * (size_t)t + a] - clo[a]) * scale)));
                     cnt[q]++;
                     for (int d = 0; d < 3; d++) { blo[q][d] = std::min(blo[q][d], T[t].lo[d]); bhi[q][d] = std::max(bhi[q][d], T[t].hi[d]); }
                 }
@@ -440,7 +749,7 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
             if (best_axis >= 0) {
                 const int a = best_axis; const float scale = (float)NB / (chi[a] - clo[a]); const float c0 = clo[a];
                 int* mid = std::partition(order.data() + j.b, order.data() + j.e, [&](int t) {
-                    return std::min(NB - 1, (int)((cen[3 * (size_t)t + a] - c0) * scale)) <= best_bin; });
+                    return std::max(0, std::min(NB - 1, (int)((cen[3 * (size_t)t + a] - c0) * scale))) <= best_bin; });
                 m = (int)(mid - order.data());
                 if (m <= j.b || m >= j.e) m = j.b + n / 2;           // (cannot happen: both sides were counted non-empty)
             } else {
@@ -469,7 +778,7 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
     };
     // the top of the tree on this thread until there are enough subtrees to hand out, then one subtree per task
     int nthreads = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char* te = getenv("DR_SAH_THREADS")) nthreads = std::min(std::max(atoi(te), 1), 64);
+    if (topt.sah_host_threads > 0) nthreads = std::min(topt.sah_host_threads, 64);
     if (N < 2048) nthreads = 1;
     std::vector<Job> jobs; jobs.push_back({ 0, N, 0 });
     while (nthreads > 1 && (int)jobs.size() < 8 * nthreads) {
@@ -492,19 +801,19 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
     parent[0] = -1;
 }
 
-void sah_topology_from_boxes(int N, const float* boxes, SahTopology& out) {
+void sah_topology_from_boxes(int N, const float* boxes, SahTopology& out, const TreeOptions& topt) {
     std::vector<TriRec> T((size_t)std::max(N, 0));
     for (int i = 0; i < N; i++) {
         std::memset(&T[i], 0, sizeof(TriRec));
         for (int a = 0; a < 3; a++) { T[i].lo[a] = boxes[6 * (size_t)i + a]; T[i].hi[a] = boxes[6 * (size_t)i + 3 + a]; }
     }
-    sah_hierarchy_host(N, T.data(), out.order, out.left, out.right, out.first, out.last, out.parent);
+    sah_hierarchy_host(N, T.data(), out.order, out.left, out.right, out.first, out.last, out.parent, topt);
     out.N = N;
 }
 
 hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[3], const float shi[3], float node_pad,
                       BvhNode* nodes, BvhNode* nodes_lh, TriRec* tri_sorted, int* n_nodes_out, BvhNode* path_rec, PathHdr* path_hdr,
-                      SahTopology* shared, BvhPair* pairs, BvhPair* pairs_lh, int* depth_out) {
+                      const TreeOptions& topt, SahTopology* shared, BvhPair* pairs, BvhPair* pairs_lh, int* depth_out) {
     hipError_t e;
     unsigned long long *keys = nullptr, *keys2 = nullptr;
     int *vals = nullptr, *vals2 = nullptr, *ibuf = nullptr;
@@ -522,7 +831,7 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
     DR_TRY(hipMalloc(&vals, sizeof(int) * N));
     DR_TRY(hipMalloc(&vals2, sizeof(int) * N));
     // left,right,first,last,flags: N-1 each; parent, esize, pre: 2N-1 each; pos: N
-    DR_TRY(hipMalloc(&ibuf, sizeof(int) * (6 * (size_t)N + 3 * nn + 1)));
+    DR_TRY(hipMalloc(&ibuf, sizeof(int) * (6 * (size_t)N + 4 * nn + 1)));
     DR_TRY(hipMalloc(&box, sizeof(float) * 6 * nn));
     {
         int* left = ibuf; int* right = ibuf + N; int* first = ibuf + 2 * (size_t)N;
@@ -531,22 +840,23 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
         int* pre = esize + nn;
         int* pos = pre + nn;
         int* depth_max = pos + N;
+        int* items = depth_max + 1;
         const int nb = (N + 255) / 256;
-        const char* km = getenv("DR_BVH_KEY");
-        const int key_mode = km ? atoi(km) : 0;
-        // which tree: the host's SAH topology pays from a few thousand patches up (64k: -7 % assembly time for a 10 ms build;
-        // the reference's own scenes, 6400 and 7712 patches: -5 % and break-even with a 1.2 - 1.6 ms build), below that the
-        // device's Morton tree; DR_BVH=lbvh|sah overrides
-        const char* bm = getenv("DR_BVH");
-        const bool sah = bm ? std::strcmp(bm, "sah") == 0 : N >= 6144;
-        if (sah) {
+        const int key_mode = topt.morton_key;
+        // which tree: the SAH topology pays from a few thousand patches up (64k: -7 % assembly time; the reference's own
+        // scenes, 6400 and 7712 patches: -5 % and break-even), below that the Morton tree; the caller (dr_options::tree) decides
+        const bool sah = topt.sah;
+        if (sah && !topt.sah_on_host) {
+            e = sah_hierarchy_device(st, N, tri, topt, vals2, left, right, first, last, parent);
+            if (e != hipSuccess) goto done;
+        } else if (sah) {
             SahTopology local;
             SahTopology& T = shared ? *shared : local;
             if (T.N != N) {
                 std::vector<TriRec> h_tri((size_t)N);
                 DR_TRY(hipMemcpyAsync(h_tri.data(), tri, sizeof(TriRec) * (size_t)N, hipMemcpyDeviceToHost, st));
                 DR_TRY(hipStreamSynchronize(st));
-                sah_hierarchy_host(N, h_tri.data(), T.order, T.left, T.right, T.first, T.last, T.parent);
+                sah_hierarchy_host(N, h_tri.data(), T.order, T.left, T.right, T.first, T.last, T.parent, topt);
                 T.N = N;
             }
             const std::vector<int>&h_order = T.order, &h_left = T.left, &h_right = T.right, &h_first = T.first, &h_last = T.last, &h_parent = T.parent;
@@ -579,11 +889,11 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
         DR_TRY(hipMemsetAsync(pre, 0xff, sizeof(int) * nn, st));
         DR_TRY(hipMemsetAsync(depth_max, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_emit, dim3((int)((nn + 255) / 256)), dim3(256), 0, st, N, left, first, last, parent, box, esize, node_pad, tri_sorted, nodes, nodes_lh, pre,
-                           pairs, pairs_lh, depth_max);
+                           pairs, pairs_lh, depth_max, items);
         DR_TRY(hipGetLastError());
         if (depth_out) DR_TRY(hipMemcpyAsync(depth_out, depth_max, sizeof(int), hipMemcpyDeviceToHost, st));
         if (path_rec && path_hdr) {
-            hipLaunchKernelGGL(k_paths, dim3(nb), dim3(256), 0, st, N, pos, left, right, parent, pre, nodes, path_rec, path_hdr);
+            hipLaunchKernelGGL(k_paths, dim3(nb), dim3(256), 0, st, N, pos, left, right, parent, pre, items, nodes, nodes_lh, path_rec, path_hdr);
             DR_TRY(hipGetLastError());
         }
         // nodes written = size of the root's subtree (a lone triangle is its own root leaf)
@@ -1019,82 +1329,26 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
                 : [bvh] "s"(bvh), [bvhlh] "s"(bvh_lh), [oct] "s"(octant), [alive] "s"(alive_m), [kx] "v"(kk.x), [ky] "v"(kk.y),    \
                   [kz] "v"(kk.z), [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z)                                        \
                 : DR_WALK_CLOBBERS, "vcc", "scc")
-#define DR_WALK_ASM(CHECK)                                                                                              \
-            asm volatile(                                                                                               \
-                "s_mov_b64 %[sexec], exec\n\t"                                                                          \
-                "s_mov_b64 exec, %[alive]\n\t"                                                                          \
-                "s_load_dwordx8 " DR_A_ALL ", %[bvh], %[off] offset:0x0\n\t"                                            \
-                "s_waitcnt lgkmcnt(0)\n"                                                                                \
-                "1:\n\t"                                                                                                \
-                "s_load_dwordx8 " DR_B_ALL ", %[bvh], %[off] offset:0x20\n\t"                                           \
-                DR_NODE_TEST_X(DR_A0, DR_A1, DR_A2, DR_A3, DR_A4, DR_A5)                                                \
-                "s_cbranch_vccz 3f\n\t"                                                                                 \
-                "s_add_u32 %[off], %[off], 32\n\t"                                                                      \
-                "s_cmp_lt_i32 " DR_A7 ", 0\n\t"                                                                         \
-                "s_cbranch_scc0 5f\n\t"                                                                                 \
-                "s_waitcnt lgkmcnt(0)\n"                                                                                \
-                "2:\n\t"                                                                                                \
-                "s_load_dwordx8 " DR_A_ALL ", %[bvh], %[off] offset:0x20\n\t"                                           \
-                DR_NODE_TEST_X(DR_B0, DR_B1, DR_B2, DR_B3, DR_B4, DR_B5)                                                \
-                "s_cbranch_vccz 4f\n\t"                                                                                 \
-                "s_add_u32 %[off], %[off], 32\n\t"                                                                      \
-                "s_cmp_lt_i32 " DR_B7 ", 0\n\t"                                                                         \
-                "s_cbranch_scc0 6f\n\t"                                                                                 \
-                "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
-                "s_branch 1b\n"                                                                                         \
-                "3:\n\t"                                                                                                \
-                "s_mov_b32 %[off], " DR_A6 "\n\t"                                                                       \
-                CHECK                                                                                                   \
-                "s_load_dwordx8 " DR_A_ALL ", %[bvh], %[off] offset:0x0\n\t"                                            \
-                "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
-                "s_branch 1b\n"                                                                                         \
-                "4:\n\t"                                                                                                \
-                "s_mov_b32 %[off], " DR_B6 "\n\t"                                                                       \
-                CHECK                                                                                                   \
-                "s_load_dwordx8 " DR_B_ALL ", %[bvh], %[off] offset:0x0\n\t"                                            \
-                "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
-                "s_branch 2b\n"                                                                                         \
-                "5:\n\t"                                                                                                \
-                "s_mov_b32 %[leaf], " DR_A7 "\n\t"                                                                      \
-                "s_branch 7f\n"                                                                                         \
-                "6:\n\t"                                                                                                \
-                "s_mov_b32 %[leaf], " DR_B7 "\n\t"                                                                      \
-                "s_branch 7f\n"                                                                                         \
-                "8:\n\t"                                                                                                \
-                "s_mov_b32 %[leaf], 0x7ffffff8\n"                                                                       \
-                "7:\n\t"                                                                                                \
-                "s_mov_b64 exec, %[sexec]\n\t"                                                                          \
-                "s_waitcnt lgkmcnt(0)"                                                                                  \
-                : [off] "+s"(off), [leaf] "=s"(leaf), [sexec] "=&s"(sexec), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),   \
-                  [t4] "=&v"(t4), [t5] "=&v"(t5)                                                                        \
-                : [bvh] "s"(bvh), [alive] "s"(alive_m), [end] "s"(end), [kx] "v"(kk.x), [ky] "v"(kk.y), [kz] "v"(kk.z), \
-                  [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z)                                                        \
-                : DR_WALK_CLOBBERS, "vcc", "scc")
-
-// Walk of one RANGE [off, end) of the threaded BVH for one wave of rays (segments [0,tmax] from org along dn);
-// returns the liveness mask with every lane cleared for which something in the range precedes its destination `hi`
-// (wave-uniform: one pair per wave).  A range is a run of whole subtrees that lie one after the other in the
-// pre-order array (the whole tree is the range [0, n_nodes*32)); every way out of a subtree lands exactly on the
-// first node after it, so leaving the range is only possible on a skip or after a leaf -- those two places compare
-// the offset with `end`, an entered interior node never does.
+// The walk of the THREADED tree from the root for one wave of rays (segments [0,tmax] from org along dn); returns the
+// liveness mask with every lane cleared for which something precedes its destination `hi` (wave-uniform: one pair per wave).
 //
 // The node index is wave-uniform.  The compiler's lowering of this loop spent ~20 scalar instructions per
 // node (the CU's single scalar unit serves all four SIMDs) beside the vector ones, so the interior-node
 // walk is written out by hand: one s_load_dwordx8 of the node at an SGPR byte offset, the node test with EXEC = the live
 // rays (9 vector instructions when the wave's rays share an octant, 12 otherwise), a branch on VCCZ, then
 // either the next node in pre-order (the first child: already loading into the other register set) or offset = skip --
-// 4 - 5 scalar instructions per node.  The hand-written stretch ends whenever a hit node is a leaf or the range is left.
+// 4 - 5 scalar instructions per node.  The hand-written stretch ends whenever a hit node is a leaf; skips that leave the tree
+// land on the sentinel node (all-space box, leaf code BVH_END), which every live lane hits: no end compare at all.
 //
-// iv / kk: the per-ray constants of the node test (the ray's 1/d clamped to +-1e18, and -(org*iv)).
-// octant: 0..7 = all live rays point into that octant (bit a set: towards -axis a), the walk from the root then uses the
-// sign-specialised test on bvh_lh; 8 (or RANGE): the general test on bvh.
-template <bool STATS, bool RANGE>
+// iv / kk: the per-ray constants of the node test (the ray's 1/d clamped to +-1e18 in units of the ray's length, and -(org*iv)).
+// octant: 0..7 = all live rays point into that octant (bit a set: towards -axis a): the sign-specialised test on bvh_lh;
+// 8: the general test on bvh.
+template <bool STATS>
 __device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restrict__ bvh, const TriRec* __restrict__ tri_sorted,
                                                          unsigned off, const unsigned end, f3 org, f3 dn, f3 inv, f3 iv, f3 kk,
                                                          float tmax, float tmax_w, int hi, unsigned long long alive_m, int& n_visit, int& n_leaf,
                                                          const BvhNode* __restrict__ bvh_lh = nullptr, int octant = 8) {
     for (;;) {
-        if (RANGE && off >= end) break;
         int leaf;
         if (STATS) {
             // counted variant of the same walk (debug builds only)
@@ -1114,14 +1368,11 @@ __device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restri
             float t0, t1, t2, t3, t4, t5;
             // two copies of the step, on node registers A and B (8 SGPRs each, fixed: DR_WALK_A/B below): while one node
             // is tested the next one in pre-order (the first child, where a hit descends to) is already being fetched
-            // into the other set; a miss reloads its own set from the skip offset (RANGE: unless that leaves the range).
-            // without ranges there is no end compare at all: skips that leave the tree land on the sentinel node
-            // (all-space box, leaf code BVH_END), which every live lane hits
+            // into the other set; a miss reloads its own set from the skip offset
             unsigned long long sexec;
-            if (RANGE) { DR_WALK_ASM("s_cmp_lt_u32 %[off], %[end]\n\ts_cbranch_scc0 8f\n\t"); }
-            else { DR_WALK_ASM_OCTANTS; }
+            DR_WALK_ASM_OCTANTS;
         }
-        if (leaf == BVH_END) break;          // the range is done (or the tree's sentinel was reached)
+        if (leaf == BVH_END) break;          // the tree's sentinel was reached
         if (STATS) n_leaf++;
         const unsigned long long blocked_m = leaf_blocked_mask(tri_sorted, leaf, org, dn, inv, tmax, hi, alive_m);
         alive_m &= ~blocked_m;
@@ -1227,12 +1478,12 @@ __device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restri
                   [kz] "v"(kk.z), [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z)                                        \
                 : DR_WALK_CLOBBERS, "vcc", "scc", "m0")
 
+// stk / sp: the stack on entry (lanes 0 .. sp-1 of stk): {0} = the root's record for a walk of the whole tree
 template <bool STATS>
 __device__ __forceinline__ unsigned long long walk_pairs(const BvhPair* __restrict__ pairs, const BvhPair* __restrict__ pairs_lh,
                                                          const TriRec* __restrict__ tri_sorted, f3 org, f3 dn, f3 inv, f3 iv, f3 kk,
-                                                         float tmax, int hi, unsigned long long alive_m, int octant, int& n_visit, int& n_leaf) {
-    int stk = 0;            // lane 0 = the root's record (offset 0)
-    unsigned sp = 1u;
+                                                         float tmax, int hi, unsigned long long alive_m, int octant, int stk, unsigned sp,
+                                                         int& n_visit, int& n_leaf) {
     for (;;) {
         int item;
         if (STATS) {
@@ -1270,294 +1521,145 @@ __device__ __forceinline__ unsigned long long walk_pairs(const BvhPair* __restri
 }
 #undef DR_PWALK_ASM
 
-// The walk of ONE PAIR over its path records (PathHdr, dr_internal.h).  A state machine with one copy
-// of the hand-written node walk, one of the record stream and one of the leaf test:
-//   segments 0..2   path records, streamed (DR_STREAM_ASM: the next record is already loading while one is tested, their
-//                   addresses do not depend on any test): lo's records above the depth where the two paths part
-//                   [0, ell), lo's below it (ell, Dl) -- index ell, the branch that holds hi, is left out -- and hi's
-//                   below it (ell, Dh); a record whose box some live ray touches sends the walk into the subtree below
-//                   it (DR_WALK_ASM on the range [start, end)) or, for a leaf sibling, to the leaf test;
-//   then            the two patches' own leaves (one, if they share it).
-// from_root: no records (a patch deeper than PATH_RECS): one range, the whole tree.
-// Exactness: the records and the two leaves cover every leaf of the tree, each subtree is entered under the same node
-// tests as in a walk from the root -- only the ancestors' tests are not made, and every ray of the pair would pass those
-// (if one did not, this walk reaches more leaves than the walk from the root, never fewer; what is hit is decided per
-// triangle).
-#define DR_STREAM_ASM                                                                                                   \
-            asm volatile(                                                                                               \
-                "s_mov_b64 %[sexec], exec\n\t"                                                                          \
-                "s_mov_b64 exec, %[alive]\n\t"                                                                          \
+// ---------------------------------------------------------------------------------------
+// PATH RECORDS in front of the pair walk (PathHdr, dr_internal.h).  Every ray of the pair (lo, hi) starts on patch lo and
+// ends on patch hi, so it is inside every ancestor of the two patches' leaves: in a walk from the root about 22 of the 78
+// node tests per pair are of those nodes and tell nothing.  What a walk needs instead are the SIBLINGS hanging off the two
+// root-to-leaf paths -- with the two leaves they cover the whole tree -- and those are the same for every pair a patch takes
+// part in: k_paths writes them out once per patch, in root-to-leaf order, box (lower / upper corner) + item.  A pair streams
+//   lo's records above the level where the two paths part [0, ell), lo's below it (ell, Dl) -- index ell, the branch
+//   that holds hi, is left out -- and hi's below it (ell, Dh)
+// with the next record already loading while one is tested (their addresses depend on no test), PUSHES the item of every
+// record some live ray touches onto the pair walk's stack, then the two patches' own leaves (inside their boxes by
+// construction: no test), and lets the pair walk pop until the stack is empty.  (Round 2's form of this walk entered the tree
+// at every touched record and lost more in cold starts than it saved in tests; here the records only fill the stack.)
+// Exactness: records + leaves cover every leaf of the tree, each subtree is entered under the same node tests as in a walk
+// from the root -- only the ancestors' tests are not made, and if a ray would have failed one of those this walk reaches
+// more leaves than the walk from the root, never fewer; what is hit is decided per triangle.
+// Only for waves whose rays share an octant (the records are kept in lower / upper corner form only) and patches no deeper
+// than PATH_RECS; every other pair walks from the root.
+// ---------------------------------------------------------------------------------------
+#define DR_PSTREAM_VARIANT(V, TESTA, TESTB)                                                                             \
+                V "0:\n\t"                                                                                              \
                 "s_load_dwordx8 " DR_A_ALL ", %[base], %[roff] offset:0x0\n\t"                                          \
                 "s_waitcnt lgkmcnt(0)\n"                                                                                \
-                "1:\n\t"                                                                                                \
+                V "1:\n\t"                                                                                              \
                 "s_load_dwordx8 " DR_B_ALL ", %[base], %[roff] offset:0x20\n\t"                                         \
-                DR_NODE_TEST_X(DR_A0, DR_A1, DR_A2, DR_A3, DR_A4, DR_A5)                                                \
-                "s_cbranch_vccnz 5f\n\t"                                                                                 \
+                TESTA                                                                                                   \
+                "s_cbranch_vccz " V "3f\n\t"                                                                            \
+                "v_writelane_b32 %[stk], " DR_A6 ", m0\n\t"                                                             \
+                "s_add_u32 m0, m0, 1\n"                                                                                 \
+                V "3:\n\t"                                                                                              \
                 "s_add_u32 %[roff], %[roff], 32\n\t"                                                                    \
                 "s_cmp_lt_u32 %[roff], %[rend]\n\t"                                                                     \
-                "s_cbranch_scc0 8f\n\t"                                                                                 \
-                "s_waitcnt lgkmcnt(0)\n"                                                                                \
-                "2:\n\t"                                                                                                \
-                "s_load_dwordx8 " DR_A_ALL ", %[base], %[roff] offset:0x20\n\t"                                         \
-                DR_NODE_TEST_X(DR_B0, DR_B1, DR_B2, DR_B3, DR_B4, DR_B5)                                                \
-                "s_cbranch_vccnz 6f\n\t"                                                                                 \
-                "s_add_u32 %[roff], %[roff], 32\n\t"                                                                    \
-                "s_cmp_lt_u32 %[roff], %[rend]\n\t"                                                                     \
-                "s_cbranch_scc0 8f\n\t"                                                                                 \
+                "s_cbranch_scc0 99f\n\t"                                                                                \
                 "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
-                "s_branch 1b\n"                                                                                         \
-                "5:\n\t"                                                                                                \
-                "s_mov_b32 %[rs], " DR_A6 "\n\t"                                                                        \
-                "s_mov_b32 %[re], " DR_A7 "\n\t"                                                                        \
-                "s_branch 9f\n"                                                                                         \
-                "6:\n\t"                                                                                                \
-                "s_mov_b32 %[rs], " DR_B6 "\n\t"                                                                        \
-                "s_mov_b32 %[re], " DR_B7 "\n"                                                                          \
-                "9:\n\t"                                                                                                \
+                "s_load_dwordx8 " DR_A_ALL ", %[base], %[roff] offset:0x20\n\t"                                         \
+                TESTB                                                                                                   \
+                "s_cbranch_vccz " V "4f\n\t"                                                                            \
+                "v_writelane_b32 %[stk], " DR_B6 ", m0\n\t"                                                             \
+                "s_add_u32 m0, m0, 1\n"                                                                                 \
+                V "4:\n\t"                                                                                              \
                 "s_add_u32 %[roff], %[roff], 32\n\t"                                                                    \
-                "s_mov_b32 %[hit], 1\n\t"                                                                               \
-                "s_branch 7f\n"                                                                                         \
-                "8:\n\t"                                                                                                \
-                "s_mov_b32 %[hit], 0\n"                                                                                 \
-                "7:\n\t"                                                                                                \
+                "s_cmp_lt_u32 %[roff], %[rend]\n\t"                                                                     \
+                "s_cbranch_scc0 99f\n\t"                                                                                \
+                "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+                "s_branch " V "1b\n"
+#define DR_PSTREAM_OCTANT(V, SX, SY, SZ)                                                                                \
+        DR_PSTREAM_VARIANT(V,                                                                                           \
+                DR_NODE_TEST_SX(DR_SEL(SX, DR_A0, DR_A3), DR_SEL(SY, DR_A1, DR_A4), DR_SEL(SZ, DR_A2, DR_A5),           \
+                               DR_SEL(SX, DR_A3, DR_A0), DR_SEL(SY, DR_A4, DR_A1), DR_SEL(SZ, DR_A5, DR_A2)),           \
+                DR_NODE_TEST_SX(DR_SEL(SX, DR_B0, DR_B3), DR_SEL(SY, DR_B1, DR_B4), DR_SEL(SZ, DR_B2, DR_B5),           \
+                               DR_SEL(SX, DR_B3, DR_B0), DR_SEL(SY, DR_B4, DR_B1), DR_SEL(SZ, DR_B5, DR_B2)))
+#define DR_PSTREAM_ASM                                                                                                  \
+            asm(                                                                                               \
+                "s_mov_b64 %[sexec], exec\n\t"                                                                          \
+                "s_mov_b64 exec, %[alive]\n\t"                                                                          \
+                "s_mov_b32 m0, %[sp]\n\t"                                                                               \
+                "s_bitcmp1_b32 %[oct], 2\n\t"                                                                           \
+                "s_cbranch_scc1 94f\n\t"                                                                                \
+                "s_bitcmp1_b32 %[oct], 1\n\t"                                                                           \
+                "s_cbranch_scc1 92f\n\t"                                                                                \
+                "s_bitcmp1_b32 %[oct], 0\n\t"                                                                           \
+                "s_cbranch_scc1 10f\n\t"                                                                                \
+                "s_branch 00f\n"                                                                                        \
+                "92:\n\t"                                                                                               \
+                "s_bitcmp1_b32 %[oct], 0\n\t"                                                                           \
+                "s_cbranch_scc1 30f\n\t"                                                                                \
+                "s_branch 20f\n"                                                                                        \
+                "94:\n\t"                                                                                               \
+                "s_bitcmp1_b32 %[oct], 1\n\t"                                                                           \
+                "s_cbranch_scc1 96f\n\t"                                                                                \
+                "s_bitcmp1_b32 %[oct], 0\n\t"                                                                           \
+                "s_cbranch_scc1 50f\n\t"                                                                                \
+                "s_branch 40f\n"                                                                                        \
+                "96:\n\t"                                                                                               \
+                "s_bitcmp1_b32 %[oct], 0\n\t"                                                                           \
+                "s_cbranch_scc1 70f\n\t"                                                                                \
+                "s_branch 60f\n"                                                                                        \
+                DR_PSTREAM_OCTANT("0", 0, 0, 0)                                                                         \
+                DR_PSTREAM_OCTANT("1", 1, 0, 0)                                                                         \
+                DR_PSTREAM_OCTANT("2", 0, 1, 0)                                                                         \
+                DR_PSTREAM_OCTANT("3", 1, 1, 0)                                                                         \
+                DR_PSTREAM_OCTANT("4", 0, 0, 1)                                                                         \
+                DR_PSTREAM_OCTANT("5", 1, 0, 1)                                                                         \
+                DR_PSTREAM_OCTANT("6", 0, 1, 1)                                                                         \
+                DR_PSTREAM_OCTANT("7", 1, 1, 1)                                                                         \
+                "99:\n\t"                                                                                               \
+                "s_mov_b32 %[sp], m0\n\t"                                                                               \
                 "s_mov_b64 exec, %[sexec]\n\t"                                                                          \
                 "s_waitcnt lgkmcnt(0)"                                                                                  \
-                : [roff] "+s"(roff), [sexec] "=&s"(sexec), [hit] "=s"(r_hit), [rs] "=s"(r_start), [re] "=s"(r_end), [t0] "=&v"(t0), [t1] "=&v"(t1),       \
-                  [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5)                                        \
-                : [base] "s"(rbase), [alive] "s"(alive_m), [rend] "s"(rend), [kx] "v"(kk.x), [ky] "v"(kk.y), [kz] "v"(kk.z),      \
-                  [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z)                                                        \
-                : DR_WALK_CLOBBERS, "vcc", "scc")
+                : [roff] "+s"(roff), [sp] "+s"(sp), [stk] "+v"(stk), [sexec] "=&s"(sexec), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),   \
+                  [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5)                                                        \
+                : [base] "s"(rec), [rend] "s"(rend), [oct] "s"(octant), [alive] "s"(alive_m), [kx] "v"(kk.x), [ky] "v"(kk.y),      \
+                  [kz] "v"(kk.z), [ix] "v"(iv.x), [iy] "v"(iv.y), [iz] "v"(iv.z)                                        \
+                : DR_WALK_CLOBBERS, "vcc", "scc", "m0")
 
+// one stretch [roff, rend) (byte offsets from rec) of path records: the items of the touched ones onto the stack
 template <bool STATS>
-__device__ __forceinline__ unsigned long long walk_pair(const BvhNode* __restrict__ bvh, const TriRec* __restrict__ tri_sorted,
-                                                        const BvhNode* __restrict__ rec_lo, const BvhNode* __restrict__ rec_hi,
-                                                        int ell, int Dl, int Dh, int leaf_lo, int leaf_hi, bool from_root,
-                                                        unsigned end_all, f3 org, f3 dn, f3 inv, f3 iv, f3 kk, float tmax, float tmax_w, int hi,
-                                                        unsigned long long alive_m, int& n_visit, int& n_leaf, int& n_stream) {
-    unsigned off = 0u, end = from_root ? end_all : 0u;
-    int seg = from_root ? 3 : -1;                     // record segment being streamed (0..2), then 3, 4: the own leaves, 5: done
-    unsigned roff = 0u, rend = 0u;
-    const BvhNode* rbase = rec_lo;
-    if (from_root) seg = 5;
-    for (;;) {
-        int leaf = BVH_END;
-        if (off < end) {
-            // inside a subtree: the hand-written walk up to the next leaf some live ray touches, or to the end of the range
-            if (STATS) {
-                while (off < end) {
-                    const v8f raw = *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(bvh) + off);
-                    const float nc[3] = { raw[0], raw[1], raw[2] }, nh[3] = { raw[3], raw[4], raw[5] };
-                    const unsigned nd_skip = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
-                    const int nd_leaf = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
-                    n_visit++;
-                    const unsigned long long hb_m = node_hit_mask(nc, nh, iv, kk, tmax_w) & alive_m;
-                    if (hb_m == 0ull) { off = nd_skip; continue; }
-                    off += 32u;
-                    if (nd_leaf >= 0) { leaf = nd_leaf; break; }
-                }
-            } else {
-                float t0, t1, t2, t3, t4, t5;
-                unsigned long long sexec;
-                // (wave-uniform by construction; said explicitly for the compiler's divergence analysis)
-                off = (unsigned)__builtin_amdgcn_readfirstlane((int)off);
-                end = (unsigned)__builtin_amdgcn_readfirstlane((int)end);
-                DR_WALK_ASM("s_cmp_lt_u32 %[off], %[end]\n\ts_cbranch_scc0 8f\n\t");
+__device__ __forceinline__ void stream_path_records(const BvhNode* __restrict__ rec, unsigned roff, unsigned rend, f3 iv, f3 kk,
+                                                    unsigned long long alive_m, int octant, int& stk, unsigned& sp, int& n_stream) {
+    if (roff >= rend) return;
+    if (STATS) {
+        for (; roff < rend; roff += 32u) {
+            const v8f raw = *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(rec) + roff);
+            // (counted build: the general test on the record's centre / half-extent -- the same box up to rounding outwards)
+            const float nc[3] = { 0.5f * raw[0] + 0.5f * raw[3], 0.5f * raw[1] + 0.5f * raw[4], 0.5f * raw[2] + 0.5f * raw[5] };
+            const float nh[3] = { (raw[3] - raw[0]) * 0.5000001f + 1e-30f, (raw[4] - raw[1]) * 0.5000001f + 1e-30f, (raw[5] - raw[2]) * 0.5000001f + 1e-30f };
+            n_stream++;
+            if ((node_hit_mask(nc, nh, iv, kk, 1.0f) & alive_m) != 0ull) {
+                const int it = __builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
+                stk = ((int)(threadIdx.x & 63u) == (int)sp) ? it : stk;
+                sp++;
             }
-            if (leaf == BVH_END) continue;          // range done
-        } else if (roff < rend) {
-            // the records of the current segment, up to the first one some live ray touches
-            int r_hit, r_start, r_end;
-            if (STATS) {
-                r_hit = 0; r_start = 0; r_end = 0;
-                while (roff < rend) {
-                    const v8f raw = *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(rbase) + roff);
-                    const float nc[3] = { raw[0], raw[1], raw[2] }, nh[3] = { raw[3], raw[4], raw[5] };
-                    roff += 32u;
-                    n_stream++;
-                    if ((node_hit_mask(nc, nh, iv, kk, tmax_w) & alive_m) != 0ull) {
-                        r_hit = 1;
-                        r_start = __builtin_amdgcn_readfirstlane(__float_as_int(raw[6]));
-                        r_end = __builtin_amdgcn_readfirstlane(__float_as_int(raw[7]));
-                        break;
-                    }
-                }
-            } else {
-                float t0, t1, t2, t3, t4, t5;
-                unsigned long long sexec;
-                DR_STREAM_ASM;
-            }
-            if (!r_hit) continue;                                   // segment exhausted
-            if (r_end < 0) leaf = r_start;                          // a leaf sibling
-            else { off = (unsigned)r_start; end = (unsigned)r_end; continue; }
-        } else {
-            // next segment / the pair's own leaves (every ray is in their boxes: no box test)
-            seg++;
-            if (seg == 0) { rbase = rec_lo; roff = 0u; rend = (unsigned)ell * 32u; continue; }
-            if (seg == 1) { rbase = rec_lo; roff = (unsigned)(ell + 1) * 32u; rend = (unsigned)Dl * 32u; if (roff > rend) roff = rend; continue; }
-            if (seg == 2) { rbase = rec_hi; roff = (unsigned)(ell + 1) * 32u; rend = (unsigned)Dh * 32u; if (roff > rend) roff = rend; continue; }
-            if (seg == 3) leaf = leaf_lo;
-            else if (seg == 4 && leaf_hi != leaf_lo) leaf = leaf_hi;
-            else break;
         }
-        if (STATS) n_leaf++;
-        const unsigned long long blocked_m = leaf_blocked_mask(tri_sorted, leaf, org, dn, inv, tmax, hi, alive_m);
-        alive_m &= ~blocked_m;
-        if (alive_m == 0ull) break;
+    } else {
+        float t0, t1, t2, t3, t4, t5;
+        unsigned long long sexec;
+        DR_PSTREAM_ASM;
     }
-    return alive_m;
 }
-#undef DR_STREAM_ASM
-#undef DR_WALK_ASM
+#undef DR_PSTREAM_ASM
+
+// one item onto the lane stack
+__device__ __forceinline__ void lane_push(int& stk, unsigned& sp, int item) {
+    asm("s_mov_b32 m0, %[sp]\n\ts_nop 0\n\tv_writelane_b32 %[stk], %[it], m0\n\ts_add_u32 %[sp], %[sp], 1"
+                 : [stk] "+v"(stk), [sp] "+s"(sp) : [it] "s"(item) : "m0", "scc");
+}
+
 #undef DR_NODE_TEST
-
-// ---------------------------------------------------------------------------------------
-// Tile-pair shaft culling.
-//
-// All K rays of all 64 x 64 pairs of a tile pair run from a point of tile I's patches to a point of tile J's, so they
-// stay inside the convex hull of the two tiles' bounding boxes (the "shaft"; Haines & Wallace 1994).  Once per
-// workgroup one wave walks the BVH against the shaft and cuts it down to a short list of node RANGES (runs of whole
-// subtrees) that can meet it; every pair's walk (walk_range) then runs over that list instead of starting at the
-// root -- it neither re-tests, 4096 times over, the ancestors every one of these rays is inside of, nor whatever lies
-// outside the shaft.
-//
-// Exactness.  What is hit is decided per triangle by its gate and the Moller-Trumbore test, whichever way a walk got
-// to the triangle's leaf; so a walk over the list gives the brute-force answer as long as it reaches every leaf the
-// walk from the root would reach.  The walk from the root reaches a leaf iff the ray's node test accepts every
-// ancestor; that test accepts a node only if the (real-arithmetic) segment org + t*dn, t in [0,tmax] passes within
-// 1e-6*(M + D) of the node's stored box in every axis (its fma roundings are <= 6 ulp of (|c|+|org|+h)|iv|; M = max
-// |coordinate|, D = scene diagonal).  The list keeps every node whose box meets the hull of the two tile boxes grown
-// by shaft_pad_node = 5e-6*(M + D), tested with a further tolerance for the test's own roundings; and a pair only
-// uses the list when, for every live ray, the origin lies in tile I's box and the end point org + tmax*dn in tile J's
-// (each grown by shaft_pad_ray = 1e-6*(M + D)) -- checked on the very floats the walk uses, so a ray whose tmax is
-// rounding noise (a grazing destination) or whose origin offset leaves the box simply sends its pair down the walk
-// from the root.  Hence segment in hull(I', J'), accepted node within 1e-6*(M+D) of the segment => node kept.
-//
-// The shaft's planes: the six faces of the union box, and up to 12 "connecting" planes, each holding an edge of box
-// I and the parallel edge of box J: per axis a and corner type (sp, sq) of the boxes' projections along a, the plane
-// through corner(sp,sq) of both rectangles with normal (sp*|dq|, sq*|dp|) -- a supporting plane of both iff dp*sp and
-// dq*sq have opposite signs.  With d0 = max(n.cornerI, n.cornerJ), the half-space n.x <= d0 holds both boxes for ANY n
-// of that sign pattern (the support point of a box in such a direction IS that corner), so rounding in n is harmless;
-// rounding in the dot products is covered by the tolerance 1e-5*|n|_1*(M + D).
-// ---------------------------------------------------------------------------------------
-constexpr int LIST_MAX = 96;             // ranges per tile pair; more than that: the walks start at the root
-constexpr unsigned long long SHAFT_CULL = 0x3ffffull;        // lanes 0-11 connecting planes, 12-17 union box
-constexpr int SHAFT_NEAR_I = 18, SHAFT_NEAR_J = 24;           // lanes 18-23: tile I's box, 24-29: tile J's
-
-struct ShaftLane { float nx, ny, nz, d0; bool valid; };
-
-__device__ __forceinline__ float pick3(f3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
-__device__ __forceinline__ f3 sel3(bool c, f3 a, f3 b) { return f3{ c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z }; }
-
-// per-lane plane of the shaft test; I / J = the two tile boxes grown by shaft_pad_node
-__device__ __forceinline__ ShaftLane shaft_lane(int l, f3 Ilo, f3 Ihi, f3 Jlo, f3 Jhi, float tol_scale, float near_shrink) {
-    ShaftLane L;
-    float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
-    L.d0 = 0.0f; L.valid = false;
-    if (l < 12) {
-        const int a = l >> 2, p = a == 2 ? 0 : a + 1, q = a == 0 ? 2 : a - 1;
-        const bool hp = (l & 1) != 0, hq = (l & 2) != 0;
-        const float sp = hp ? 1.0f : -1.0f, sq = hq ? 1.0f : -1.0f;
-        const float Ap = pick3(sel3(hp, Ihi, Ilo), p), Aq = pick3(sel3(hq, Ihi, Ilo), q);
-        const float Bp = pick3(sel3(hp, Jhi, Jlo), p), Bq = pick3(sel3(hq, Jhi, Jlo), q);
-        const float dp = Bp - Ap, dq = Bq - Aq;
-        const float a1 = dp * sp, a2 = dq * sq;
-        L.valid = (a1 > 0.0f && a2 < 0.0f) || (a1 < 0.0f && a2 > 0.0f);
-        const float sc = 1.0f / fmaxf(fmaxf(fabsf(dp), fabsf(dq)), 1e-30f);
-        const float np_ = sp * (fabsf(dq) * sc), nq_ = sq * (fabsf(dp) * sc);
-        L.valid = L.valid && (np_ != 0.0f) && (nq_ != 0.0f);      // an underflowed component would change the sign pattern
-        L.d0 = fmaxf(np_ * Ap + nq_ * Aq, np_ * Bp + nq_ * Bq);
-        n0 = p == 0 ? np_ : (q == 0 ? nq_ : 0.0f);
-        n1 = p == 1 ? np_ : (q == 1 ? nq_ : 0.0f);
-        n2 = p == 2 ? np_ : (q == 2 ? nq_ : 0.0f);
-    } else if (l < 30) {
-        const int k = (l - 12) % 6, which = (l - 12) / 6;          // 0 union, 1 tile I, 2 tile J
-        const int a = k >> 1;
-        const bool pos = (k & 1) != 0;
-        const float ilo = pick3(Ilo, a), ihi = pick3(Ihi, a), jlo = pick3(Jlo, a), jhi = pick3(Jhi, a);
-        float lo = which == 0 ? fminf(ilo, jlo) : (which == 1 ? ilo : jlo);
-        float hi = which == 0 ? fmaxf(ihi, jhi) : (which == 1 ? ihi : jhi);
-        if (which != 0) {       // "near a tile" = meets the tile's box shrunk towards its middle (a heuristic only: it decides what is split)
-            const float sh = near_shrink * (hi - lo);
-            lo += sh; hi -= sh;
-        }
-        const float sg = pos ? 1.0f : -1.0f;
-        n0 = a == 0 ? sg : 0.0f; n1 = a == 1 ? sg : 0.0f; n2 = a == 2 ? sg : 0.0f;
-        L.d0 = pos ? hi : -lo;
-        L.valid = true;
-    }
-    L.nx = n0; L.ny = n1; L.nz = n2;
-    L.d0 += 1e-5f * ((fabsf(n0) + fabsf(n1)) + fabsf(n2)) * tol_scale;
-    return L;
-}
-
-// which of the lanes' planes have the node's box entirely on their outer side
-__device__ __forceinline__ unsigned long long shaft_out_mask(const ShaftLane& L, const v8f nd) {
-    const float s = ((L.nx * nd[0] + L.ny * nd[1]) + L.nz * nd[2]) - ((fabsf(L.nx) * nd[3] + fabsf(L.ny) * nd[4]) + fabsf(L.nz) * nd[5]);
-    return __builtin_amdgcn_ballot_w64(L.valid && (s > L.d0));
-}
-
-__device__ __forceinline__ v8f load_node(const BvhNode* bvh, unsigned off) {
-    return *reinterpret_cast<const v8f*>(reinterpret_cast<const char*>(bvh) + off);
-}
-
-// One wave (all 64 lanes, uniform control flow).  Writes the ranges to sList and returns their number;
-// stats[0] += nodes looked at.
-__device__ __forceinline__ int build_shaft_list(const BvhNode* __restrict__ bvh, unsigned end_all, f3 Ilo, f3 Ihi, f3 Jlo, f3 Jhi,
-                                                float tol_scale, float near_shrink, unsigned min_bytes, uint2* sList, int lane, int& n_looked) {
-    const ShaftLane L = shaft_lane(lane, Ilo, Ihi, Jlo, Jhi, tol_scale, near_shrink);
-    unsigned off = 0u, prev_end = 0xffffffffu;
-    int n = 0;
-    bool overflow = false;
-    while (off < end_all) {
-        const v8f nd = load_node(bvh, off);
-        const unsigned skip = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(nd[6]));
-        const int tri = __builtin_amdgcn_readfirstlane(__float_as_int(nd[7]));
-        const unsigned long long m = shaft_out_mask(L, nd);
-        n_looked++;
-        if (m & SHAFT_CULL) { off = skip; continue; }           // outside the shaft: nothing below it can be touched
-        bool emit = true;
-        if (tri < 0 && skip - off > min_bytes) {
-            // split a big subtree when that prunes: always near the two tiles (every ray is inside these nodes, their
-            // tests are pure overhead), elsewhere when a child lies outside the shaft
-            const bool near = ((m >> SHAFT_NEAR_I) & 0x3full) == 0ull || ((m >> SHAFT_NEAR_J) & 0x3full) == 0ull;
-            if (near) emit = false;
-            else {
-                const v8f c0 = load_node(bvh, off + 32u);
-                const unsigned c1_off = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(c0[6]));
-                const v8f c1 = load_node(bvh, c1_off);
-                n_looked += 2;
-                if ((shaft_out_mask(L, c0) & SHAFT_CULL) || (shaft_out_mask(L, c1) & SHAFT_CULL)) emit = false;
-            }
-        }
-        if (!emit) { off += 32u; continue; }
-        if (n > 0 && prev_end == off) {
-            if (lane == 0) sList[n - 1].y = skip;               // runs on from the previous range
-        } else {
-            if (n == LIST_MAX) { overflow = true; break; }
-            if (lane == 0) sList[n] = make_uint2(off, skip);
-            n++;
-        }
-        prev_end = skip;
-        off = skip;
-    }
-    if (overflow) {
-        if (lane == 0) sList[0] = make_uint2(0u, end_all);
-        n = 1;
-    }
-    return n;
-}
 
 // STATS builds count BVH visits with global atomics inside the pair loop; that store makes
 // the compiler give up scalar (SMEM) loads for nodes and triangles, so it is a separate,
 // debug-only instantiation.
 // amdgpu_num_sgpr(82) -> 80 SGPRs in the code object: the most with which a CU admits 8 blocks of 256 threads (the rest is
 // parked in VGPR lanes outside the pair loop); with 64 VGPRs and 19.7 KB of LDS that is 8 waves per SIMD, the hardware's maximum
-// WALK: 3 = the walk over the sibling-pair records (walk_pairs; shipped); 0 = the threaded tree from the root (round 2's; trees
-// deeper than the pair walk's stack); 1 = over the tile pair's shaft list (build_shaft_list); 2 = over the two patches' path
-// records (walk_pair).  1 and 2 are exact and measured slower: profiles/r02/assembly_notes.md.
+// WALK: 3 = the walk over the sibling-pair records from the root (walk_pairs); 2 = the same walk with its stack filled from the two
+// patches' path records (stream_path_records); 0 = the threaded tree from the root (round 2's; trees deeper than the pair walk's
+// stack).  (Round 2 also had tile-pair shaft lists: exact, measured slower, removed; profiles/r02/assembly_notes.md.)
 template <int NT, bool STATS, int WALK>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82), amdgpu_waves_per_eu(8, 8))) void k_ff_tiles(TileParams P) {
-    constexpr bool SHAFT = (WALK == 1), PATHS = (WALK == 2);
+    constexpr bool PATHS = (WALK == 2);
     const int t = blockIdx.x;
     const int o = P.tile0 + blockIdx.y;
     const bool t_owned = (t >= P.tile0) && (t < P.tile0 + P.nOwnedTiles);
@@ -1591,9 +1693,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82), amdgpu_wave
     __shared__ int sCount;
     unsigned short* const sQueueB = reinterpret_cast<unsigned short*>(&sRec[0][0][0]);
     static_assert(sizeof(float) * 2 * TILE * REC_STRIDE >= sizeof(unsigned short) * TILE * TILE / 2, "second half of the queue does not fit the records");
-    __shared__ float sBox[2][6];                        // union of the gate boxes of the I / J tile's patches: lo[3], hi[3]
-    __shared__ uint2 sList[LIST_MAX];                   // the tile pair's candidate node ranges (build_shaft_list)
-    __shared__ int sNList;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1604,24 +1703,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82), amdgpu_wave
         int r = (x - side * TILE * 20) / 20, c = x % 20;
         int g = (side ? J0 : I0) + r;
         sRec[side][r][c] = (g < P.N) ? reinterpret_cast<const float*>(P.patch + g)[c] : 0.0f;
-    }
-    if (SHAFT && tid < 2 * TILE) {
-        // bounding boxes of the two tiles (waves 0 and 1): every ray of the tile pair starts in one and ends in the other
-        const int side = tid >> 6;
-        const int g = (side ? J0 : I0) + lane;
-        float b[6] = { INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY };
-        if (g < P.N) {
-#pragma unroll
-            for (int a = 0; a < 3; a++) { b[a] = P.tri[g].lo[a]; b[3 + a] = P.tri[g].hi[a]; }
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1)
-#pragma unroll
-            for (int a = 0; a < 3; a++) { b[a] = fminf(b[a], __shfl_xor(b[a], o)); b[3 + a] = fmaxf(b[3 + a], __shfl_xor(b[3 + a], o)); }
-        if (lane == 0) {
-#pragma unroll
-            for (int a = 0; a < 6; a++) sBox[side][a] = b[a];
-        }
     }
     __syncthreads();
 
@@ -1669,33 +1750,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82), amdgpu_wave
     // every ray starts inside the root's box: an interior root is entered without its test (the walk starts at its first child)
     const unsigned root_off = P.n_nodes >= 3 ? (unsigned)sizeof(BvhNode) : 0u;
 
-    // ---- the tile pair's shaft: the node ranges its walks run over --------------------------------
-    const bool use_shaft = SHAFT && (n_act > 0) && (P.trace != 0);
-    if (use_shaft) {
-        if (tid < 64) {
-            const float pn = P.shaft_pad_node;
-            const f3 Ilo = f3{ sBox[0][0] - pn, sBox[0][1] - pn, sBox[0][2] - pn }, Ihi = f3{ sBox[0][3] + pn, sBox[0][4] + pn, sBox[0][5] + pn };
-            const f3 Jlo = f3{ sBox[1][0] - pn, sBox[1][1] - pn, sBox[1][2] - pn }, Jhi = f3{ sBox[1][3] + pn, sBox[1][4] + pn, sBox[1][5] + pn };
-            int n_looked = 0;
-            const int nl = build_shaft_list(P.bvh, end_all, Ilo, Ihi, Jlo, Jhi, P.shaft_tol, P.shaft_near_shrink, (unsigned)P.shaft_min_bytes, sList, lane, n_looked);
-            if (lane == 0) {
-                sNList = nl;
-                if (STATS && P.dbg_lo < 0) {
-                    atomicAdd(P.pairs_traced + 8, (unsigned long long)nl);
-                    atomicAdd(P.pairs_traced + 9, (unsigned long long)n_looked);
-                    atomicAdd(P.pairs_traced + 11, 1ull);
-                }
-            }
-        }
-        __syncthreads();
-    }
-
     // ---- visibility: one wave per pair, one lane per ray, wave-uniform BVH walk ---------
     if (n_act > 0 && P.trace) {
         // queue entries are dealt round-robin to the block's waves (all indices wave-uniform)
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int n_act_u = __builtin_amdgcn_readfirstlane(n_act);
-        const int n_list = use_shaft ? __builtin_amdgcn_readfirstlane(sNList) : 1;
         for (int q = wave; q < n_act_u; q += NT / 64) {
             const int p = __builtin_amdgcn_readfirstlane((int)(q < TILE * TILE / 2 ? sQueue[q] : sQueueB[q - TILE * TILE / 2]));
             const int i = p >> 6, j = p & 63;
@@ -1706,24 +1765,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82), amdgpu_wave
             const f3 ha = ld3(Th.a), he1 = ld3(Th.e1), he2 = ld3(Th.e2);
             int count = 0;
             int n_visit = 0, n_leaf = 0, n_stream = 0;
-            // the two patches' path records (PathHdr): where their root-to-leaf paths part, which records to stream
-            int ell = 0, pDl = 0, pDh = 0, leaf_lo = 0, leaf_hi = 0;
-            bool no_paths = true;
-            const BvhNode *rec_lo = nullptr, *rec_hi = nullptr;
-            if (PATHS && P.path_hdr != nullptr) {
-                const PathHdr hl = P.path_hdr[lo], hh = P.path_hdr[hi];
-                const int Dl = __builtin_amdgcn_readfirstlane(hl.depth), Dh = __builtin_amdgcn_readfirstlane(hh.depth);
-                if (Dl >= 0 && Dh >= 0) {
-                    no_paths = false;
-                    const int m = min(Dl, Dh);
-                    const unsigned tl = (unsigned)__builtin_amdgcn_readfirstlane((int)hl.turns), th = (unsigned)__builtin_amdgcn_readfirstlane((int)hh.turns);
-                    const unsigned x = (tl ^ th) & (m >= 32 ? 0xffffffffu : ((1u << m) - 1u));
-                    ell = x ? __builtin_ctz(x) : m;                 // levels the two paths share
-                    pDl = Dl; pDh = Dh;
-                    leaf_lo = __builtin_amdgcn_readfirstlane(hl.leaf); leaf_hi = __builtin_amdgcn_readfirstlane(hh.leaf);
-                    rec_lo = P.path_rec + (size_t)lo * PATH_RECS; rec_hi = P.path_rec + (size_t)hi * PATH_RECS;
-                }
-            }
             for (int k0 = 0; k0 < P.K; k0 += 64) {
                 const int k = k0 + lane;
                 bool alive = k < P.K;
@@ -1754,49 +1795,51 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82), amdgpu_wave
                                       __builtin_amdgcn_fmed3f(inv.z, -1e18f, 1e18f) * ts };
                     const f3 kk = f3{ -(org.x * iv.x), -(org.y * iv.y), -(org.z * iv.z) };
                     const float tmax_w = 1.0f;
-                    // The list only serves rays that really run from tile I's box to tile J's (see "Exactness" above):
-                    // one ray outside (a tmax that is rounding noise, an origin offset that leaves the box) and this
-                    // pair walks from the root.
-                    bool from_root = !use_shaft;
-                    if (use_shaft) {
-                        const f3 ep = f3{ __builtin_fmaf(dn.x, tmax, org.x), __builtin_fmaf(dn.y, tmax, org.y), __builtin_fmaf(dn.z, tmax, org.z) };
-                        const float pr = P.shaft_pad_ray;
-                        bool inb = (org.x >= sBox[0][0] - pr) & (org.y >= sBox[0][1] - pr) & (org.z >= sBox[0][2] - pr) &
-                                   (org.x <= sBox[0][3] + pr) & (org.y <= sBox[0][4] + pr) & (org.z <= sBox[0][5] + pr) &
-                                   (ep.x >= sBox[1][0] - pr) & (ep.y >= sBox[1][1] - pr) & (ep.z >= sBox[1][2] - pr) &
-                                   (ep.x <= sBox[1][3] + pr) & (ep.y <= sBox[1][4] + pr) & (ep.z <= sBox[1][5] + pr);
-                        from_root = (__builtin_amdgcn_ballot_w64(alive && !inb) != 0ull);
-                        if (STATS && from_root && lane == 0 && P.dbg_lo < 0) atomicAdd(P.pairs_traced + 10, 1ull);
+                    // do all live rays point into one octant?  (they run from one patch to one patch: nearly always)
+                    int octant = 8;
+                    if ((WALK == 0 ? (const void*)P.bvh_lh : (const void*)P.pairs_lh) != nullptr) {
+                        const unsigned long long nx = alive_m & __builtin_amdgcn_fcmpf(dn.x, 0.0f, 4), ny = alive_m & __builtin_amdgcn_fcmpf(dn.y, 0.0f, 4),
+                                                 nz = alive_m & __builtin_amdgcn_fcmpf(dn.z, 0.0f, 4);
+                        if ((nx == 0ull || nx == alive_m) && (ny == 0ull || ny == alive_m) && (nz == 0ull || nz == alive_m))
+                            octant = (nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0);
                     }
-                    if (WALK == 0 || WALK == 3) {
-                        // the whole tree, sentinel-terminated: no end-of-range compares in the walk
-                        // do all live rays point into one octant?  (they run from one patch to one patch: nearly always)
-                        int octant = 8;
-                        if ((WALK == 3 ? (const void*)P.pairs_lh : (const void*)P.bvh_lh) != nullptr) {
-                            const unsigned long long nx = alive_m & __builtin_amdgcn_fcmpf(dn.x, 0.0f, 4), ny = alive_m & __builtin_amdgcn_fcmpf(dn.y, 0.0f, 4),
-                                                     nz = alive_m & __builtin_amdgcn_fcmpf(dn.z, 0.0f, 4);
-                            if ((nx == 0ull || nx == alive_m) && (ny == 0ull || ny == alive_m) && (nz == 0ull || nz == alive_m))
-                                octant = (nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0);
+                    octant = __builtin_amdgcn_readfirstlane(octant);
+                    if (STATS && octant == 8 && lane == 0 && P.dbg_lo < 0) atomicAdd(P.pairs_traced + 13, 1ull);
+                    if (WALK == 0) {
+                        // the threaded tree, sentinel-terminated: no end-of-range compares in the walk
+                        alive_m = walk_range<STATS>(P.bvh, P.tri_sorted, root_off, end_all, org, dn, inv, iv, kk, tmax, tmax_w, hi, alive_m, n_visit, n_leaf,
+                                                    P.bvh_lh, octant);
+                    } else {
+                        int stk = 0;                  // lane 0 = the root's record (offset 0)
+                        unsigned sp = 1u;
+                        if (PATHS && P.path_hdr != nullptr && octant < 8) {
+                            // the two patches' path records (PathHdr): where their root-to-leaf paths part, which records to stream
+                            // (looked up here, not ahead of the ray set-up: nothing of it is live across that)
+                            const PathHdr hl = P.path_hdr[lo], hh = P.path_hdr[hi];
+                            const int Dl = __builtin_amdgcn_readfirstlane(hl.depth), Dh = __builtin_amdgcn_readfirstlane(hh.depth);
+                            if (Dl >= 0 && Dh >= 0) {
+                                const int m = min(Dl, Dh);
+                                const unsigned long long tl = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)hl.turns_hi) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)hl.turns_lo);
+                                const unsigned long long th = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)hh.turns_hi) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)hh.turns_lo);
+                                const unsigned long long x = (tl ^ th) & (m >= 64 ? ~0ull : ((1ull << m) - 1ull));
+                                const unsigned ell = (unsigned)(x ? __builtin_ctzll(x) : m);                 // levels the two paths share
+                                const unsigned bl = (unsigned)lo * (unsigned)(PATH_RECS * sizeof(BvhNode)), bh = (unsigned)hi * (unsigned)(PATH_RECS * sizeof(BvhNode));
+                                const int leaf_lo = __builtin_amdgcn_readfirstlane(hl.leaf), leaf_hi = __builtin_amdgcn_readfirstlane(hh.leaf);
+                                // the stack from the path records: touched siblings, then the two patches' own leaves
+                                sp = 0u;
+                                stream_path_records<STATS>(P.path_rec, bl, bl + ell * 32u, iv, kk, alive_m, octant, stk, sp, n_stream);
+                                stream_path_records<STATS>(P.path_rec, bl + (ell + 1u) * 32u, bl + (unsigned)Dl * 32u, iv, kk, alive_m, octant, stk, sp, n_stream);
+                                stream_path_records<STATS>(P.path_rec, bh + (ell + 1u) * 32u, bh + (unsigned)Dh * 32u, iv, kk, alive_m, octant, stk, sp, n_stream);
+                                if (STATS) {
+                                    stk = ((int)lane == (int)sp) ? leaf_hi : stk; sp++;
+                                    if (leaf_lo != leaf_hi) { stk = ((int)lane == (int)sp) ? leaf_lo : stk; sp++; }
+                                } else {
+                                    lane_push(stk, sp, leaf_hi);
+                                    if (leaf_lo != leaf_hi) lane_push(stk, sp, leaf_lo);
+                                }
+                            }
                         }
-                        octant = __builtin_amdgcn_readfirstlane(octant);
-                        if (STATS && octant == 8 && lane == 0 && P.dbg_lo < 0) atomicAdd(P.pairs_traced + 13, 1ull);
-                        if (WALK == 3)
-                            alive_m = walk_pairs<STATS>(P.pairs, P.pairs_lh, P.tri_sorted, org, dn, inv, iv, kk, tmax, hi, alive_m, octant, n_visit, n_leaf);
-                        else
-                            alive_m = walk_range<STATS, false>(P.bvh, P.tri_sorted, root_off, end_all, org, dn, inv, iv, kk, tmax, tmax_w, hi, alive_m, n_visit, n_leaf,
-                                                               P.bvh_lh, octant);
-                    }
-                    if (PATHS) {
-                        alive_m = walk_pair<STATS>(P.bvh, P.tri_sorted, rec_lo, rec_hi, ell, pDl, pDh, leaf_lo, leaf_hi, no_paths, end_all,
-                                                   org, dn, inv, iv, kk, tmax, tmax_w, hi, alive_m, n_visit, n_leaf, n_stream);
-                    }
-                    const int ne = !SHAFT ? 0 : (from_root ? 1 : n_list);
-                    for (int e = 0; e < ne; e++) {
-                        const uint2 rg = sList[e];
-                        const unsigned r_off = from_root ? 0u : (unsigned)__builtin_amdgcn_readfirstlane((int)rg.x);
-                        const unsigned r_end = from_root ? end_all : (unsigned)__builtin_amdgcn_readfirstlane((int)rg.y);
-                        alive_m = walk_range<STATS, true>(P.bvh, P.tri_sorted, r_off, r_end, org, dn, inv, iv, kk, tmax, tmax_w, hi, alive_m, n_visit, n_leaf);
-                        if (alive_m == 0ull) break;
+                        alive_m = walk_pairs<STATS>(P.pairs, P.pairs_lh, P.tri_sorted, org, dn, inv, iv, kk, tmax, hi, alive_m, octant, stk, sp, n_visit, n_leaf);
                     }
                 }
                 count += __popcll(alive_m);
@@ -1870,15 +1913,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(82), amdgpu_wave
 
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p) {
     dim3 grid(p.nT, p.nOwnedTiles);
-    const int walk = p.shaft ? 1 : (p.path_hdr ? 2 : (p.pairs ? 3 : 0));
+    const int walk = !p.pairs ? 0 : (p.path_hdr ? 2 : 3);
     if (p.stats & 1) {
-        if (walk == 1) hipLaunchKernelGGL((k_ff_tiles<256, true, 1>), grid, dim3(256), 0, st, p);
-        else if (walk == 2) hipLaunchKernelGGL((k_ff_tiles<256, true, 2>), grid, dim3(256), 0, st, p);
+        if (walk == 2) hipLaunchKernelGGL((k_ff_tiles<256, true, 2>), grid, dim3(256), 0, st, p);
         else if (walk == 3) hipLaunchKernelGGL((k_ff_tiles<256, true, 3>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((k_ff_tiles<256, true, 0>), grid, dim3(256), 0, st, p);
         return hipGetLastError();
     }
-    if (walk == 1) { hipLaunchKernelGGL((k_ff_tiles<256, false, 1>), grid, dim3(256), 0, st, p); return hipGetLastError(); }
     if (walk == 2) { hipLaunchKernelGGL((k_ff_tiles<256, false, 2>), grid, dim3(256), 0, st, p); return hipGetLastError(); }
     if (walk == 3) { hipLaunchKernelGGL((k_ff_tiles<256, false, 3>), grid, dim3(256), 0, st, p); return hipGetLastError(); }
     // (512 and 1024 threads per workgroup -- more waves sharing a queue -- measured 5 % and 14 % slower at 64k patches)

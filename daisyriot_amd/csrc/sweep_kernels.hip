@@ -18,8 +18,6 @@
 // a host round trip per pass (check_convergence, vs/Lightning.h:145-151, 255-261, 336-340).
 #include "dr_internal.h"
 
-#include <cstdlib>
-
 namespace dr {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -63,8 +61,14 @@ __device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomi
 
 // one arrival at a counter that `expected` blocks arrive at; true for the block that arrives last (it also rearms the
 // counter for the next pass)
-__device__ __forceinline__ bool arrive_last(unsigned* counter, unsigned expected, int* sFlag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have left
+// HARDWARE ASSUMPTION of the unfenced form: under the HIP / LLVM memory model relaxed stores + a relaxed
+// ticket do not order the data before the ticket; on gfx950 they do, because sc1 stores write through to the device's coherence
+// point (L2 / memory side), s_waitcnt vmcnt(0) returns only once they are acknowledged there, and sc1 loads are served from
+// there.  `fenced` (dr_options::sweep_fenced) is the memory-model form of the same hand-off -- an agent-scope release fence in
+// every thread before the ticket, an acquire fence in the last block after it -- kept for cross-checks (tests compare the two).
+__device__ __forceinline__ bool arrive_last(unsigned* counter, unsigned expected, int* sFlag, int fenced) {
+    if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have left
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned t = atomicAdd(counter, 1u);
@@ -73,7 +77,37 @@ __device__ __forceinline__ bool arrive_last(unsigned* counter, unsigned expected
         *sFlag = last ? 1 : 0;
     }
     __syncthreads();
-    return *sFlag != 0;
+    const bool last = *sFlag != 0;
+    if (fenced && last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return last;
+}
+
+// In-pass exchange (SweepParams::peers): called by the LAST block of a pass, all threads, after every block has fenced its
+// stores into the peers' buffers at system scope and arrived: the pass number into slot `rank` of every device's sequence array.
+__device__ __forceinline__ void publish_pass(const SweepParams& P) {
+    __threadfence_system();
+    if ((int)threadIdx.x < P.n_peers && P.peer_seq[threadIdx.x])
+        __hip_atomic_store(&P.peer_seq[threadIdx.x][P.rank], P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The gate in front of the next pass: ONE thread per rank of ONE block (it can never crowd out the kernels it waits for, which
+// may share the device in a rehearsal) polls this device's sequence array until every rank has published pass `want`.  A wait
+// that does not end within ~5 s (a peer died) sets err[0] and lets the stream go on: the host reports it (dr_group_solver_*).
+__global__ void k_wait_peers(const unsigned* __restrict__ seq_local, int world, unsigned want, int* __restrict__ err) {
+    const int r = threadIdx.x;
+    if (r >= world) return;
+    const unsigned long long t0 = wall_clock64();            // 100 MHz
+    for (;;) {
+        const unsigned have = __hip_atomic_load(&seq_local[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int)(have - want) >= 0) return;
+        if (wall_clock64() - t0 > 500000000ull) { err[0] = 1; return; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+hipError_t launch_wait_peers(hipStream_t st, const unsigned* seq_local, int world, unsigned want, int* err) {
+    hipLaunchKernelGGL(k_wait_peers, dim3(1), dim3(64), 0, st, seq_local, world, want, err);
+    return hipGetLastError();
 }
 
 // What follows the stream over F in both pass kernels.  sGf[ROWSB][SPAD] (LDS) holds the block's rows' sums F*R over
@@ -94,7 +128,7 @@ __device__ __forceinline__ void sweep_tail(const SweepParams& P, float* sGf, flo
             const int row = row0b + rl;
             if (row < P.nrows) st_agent(&P.Gpart[((size_t)blockIdx.y * P.nrows + row) * S + s2], sGf[rl * SPAD + s2]);
         }
-        if (!arrive_last(&P.tickets[1 + blockIdx.x], gridDim.y, sFlag)) return;
+        if (!arrive_last(&P.tickets[1 + blockIdx.x], gridDim.y, sFlag, P.tune.fenced)) return;
         for (int e = tid; e < ROWSB * S; e += NT) {
             const int rl = e / S, s2 = e % S;
             const int row = row0b + rl;
@@ -112,11 +146,21 @@ __device__ __forceinline__ void sweep_tail(const SweepParams& P, float* sGf, flo
         if (row < P.nrows) {
             const float* Mi = P.M + (size_t)P.mat[row] * S * S + so * S;
             for (int s2 = 0; s2 < S; s2++) v = fmaf(Mi[s2], sGf[rl * SPAD + s2], v);
-            P.Rout[(size_t)P.rank * P.cstride + (size_t)so * P.rpr + row] = v;
+            const size_t at = (size_t)P.rank * P.cstride + (size_t)so * P.rpr + row;
+            P.Rout[at] = v;
+            for (int q = 0; q < P.n_peers; q++)
+                if (P.peers[q]) P.peers[q][at] = v;              // straight into the other devices' buffers (in-pass exchange)
             float* b = P.B + (size_t)so * P.rpr + row;
             *b = *b + v;
         }
         sV[so * ROWSB + rl] = v;
+    }
+    if (P.n_peers > 0 && !P.want_sums) {
+        // no sums asked for, but the pass still has to say when ALL of it has landed everywhere: the same hand-off, without sums
+        __threadfence_system();
+        if (!arrive_last(&P.tickets[0], gridDim.x, sFlag, P.tune.fenced)) return;
+        publish_pass(P);
+        return;
     }
     // the per-bin sums of the new residual are only formed for passes that ask for them (dr_solver_converge): the
     // hand-off below holds every block for a few microseconds, about 1 % of a 64k-row pass
@@ -127,7 +171,8 @@ __device__ __forceinline__ void sweep_tail(const SweepParams& P, float* sGf, flo
         for (int rl = 0; rl < ROWSB; rl++) a += (double)sV[tid * ROWSB + rl];
         st_agent(&P.blk_sums[(size_t)blockIdx.x * S + tid], a);
     }
-    if (!arrive_last(&P.tickets[0], gridDim.x, sFlag)) return;
+    if (P.n_peers > 0) __threadfence_system();       // this block's stores into the peers' buffers
+    if (!arrive_last(&P.tickets[0], gridDim.x, sFlag, P.tune.fenced)) return;
     if (tid < 256) {
         const int s2 = tid >> 4, j = tid & 15;
         double a = 0.0;
@@ -139,9 +184,13 @@ __device__ __forceinline__ void sweep_tail(const SweepParams& P, float* sGf, flo
     if (tid < S) {
         double a = 0.0;
         for (int j = 0; j < 16; j++) a += sD[tid * 16 + j];
-        reinterpret_cast<double*>(P.Rout + (size_t)P.rank * P.cstride + (size_t)S * P.rpr)[tid] = a;
+        const size_t at = (size_t)P.rank * P.cstride + (size_t)S * P.rpr;
+        reinterpret_cast<double*>(P.Rout + at)[tid] = a;
+        for (int q = 0; q < P.n_peers; q++)
+            if (P.peers[q]) reinterpret_cast<double*>(P.peers[q] + at)[tid] = a;
     }
     if (tid == 0) P.ctl[0] = P.ctl[0] + 1;
+    if (P.n_peers > 0) { __syncthreads(); publish_pass(P); }
 }
 
 // S bins, RR rows per wave, NW waves per block, CPL float4 column groups per lane per row
@@ -164,7 +213,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_sweep(SweepParams P) {
     // converged: this pass and every pass queued behind it does nothing (latched in ctl[1]: the host keeps flipping the two
     // residual buffers per queued pass, and the older of the two has NOT converged)
     if (P.conv_mode != 0 && (P.ctl[1] != 0 || residual_converged(P))) {
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.ctl[1] = 1;
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            if (threadIdx.x == 0) P.ctl[1] = 1;
+            if (P.n_peers > 0) publish_pass(P);        // (the gates of the passes queued behind this one still wait for its number)
+        }
         return;
     }
 
@@ -355,7 +407,10 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_mfma(SweepParams P) {
     // converged: this pass and every pass queued behind it does nothing (latched in ctl[1]: the host keeps flipping the two
     // residual buffers per queued pass, and the older of the two has NOT converged)
     if (P.conv_mode != 0 && (P.ctl[1] != 0 || residual_converged(P))) {
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.ctl[1] = 1;
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            if (threadIdx.x == 0) P.ctl[1] = 1;
+            if (P.n_peers > 0) publish_pass(P);        // (the gates of the passes queued behind this one still wait for its number)
+        }
         return;
     }
     const int S = P.S;
@@ -513,31 +568,24 @@ static hipError_t launch_cfg(hipStream_t st, const SweepParams& p) {
 // single pass is fastest; below that, cut columns until there are about 1024 blocks, each block
 // keeping at least 8 tiles (the ranges need not be equal).  Measured at N = 65 536 on one
 // MI355X (profiles/r01/sweep_shards.md): 8192 rows 0.437 ms unsplit -> 0.342 ms with 4 ranges.
-// rows per wave of k_sweep: 8 (4 above 8 bins: the accumulators are RR*S registers); DR_SWEEP_RR=4 tries 4 below too
-static int sweep_rr(int S) {
-    static int rr = -1;
-    if (rr < 0) { const char* e = getenv("DR_SWEEP_RR"); rr = e ? atoi(e) : 8; }
-    return (S <= 8 && rr != 4) ? 8 : 4;
-}
+// rows per wave of k_sweep: 8 (4 above 8 bins: the accumulators are RR*S registers); SweepTuning::rows_per_wave = 4 tries 4 below too
+static int sweep_rr(int S, const SweepTuning& t) { return (S <= 8 && t.rows_per_wave != 4) ? 8 : 4; }
 
 // rows per workgroup of the pass kernel launch_sweep picks: k_sweep: 4 waves x 8 rows; k_sweep_mfma: 4 x 16
-static int sweep_rows_per_block(int S) {
-    static int mfma = -1;
-    if (mfma < 0) { const char* e = getenv("DR_SWEEP_MFMA"); mfma = e ? atoi(e) : 1; }
-    if (S > 8 && mfma) return 4 * MT_ROWS;
-    return 4 * sweep_rr(S);
+static int sweep_rows_per_block(int S, const SweepTuning& t) {
+    if (S > 8 && t.mfma) return 4 * MT_ROWS;
+    return 4 * sweep_rr(S, t);
 }
-int sweep_row_blocks(int nrows, int S) {
-    const int rpb = sweep_rows_per_block(S);
+int sweep_row_blocks(int nrows, int S, const SweepTuning& t) {
+    const int rpb = sweep_rows_per_block(S, t);
     return (nrows + rpb - 1) / rpb;
 }
 
-int sweep_ksplit(int nrows, int S, int total_cols) {
-    const int rows_per_block = sweep_rows_per_block(S);
+int sweep_ksplit(int nrows, int S, int total_cols, const SweepTuning& t) {
+    const int rows_per_block = sweep_rows_per_block(S, t);
     const int row_blocks = (nrows + rows_per_block - 1) / rows_per_block;
     const int ntiles = total_cols / 256;
-    static int forced = -2;
-    if (forced == -2) { const char* e = getenv("DR_SWEEP_KSPLIT"); forced = e ? atoi(e) : -1; }
+    const int forced = t.ksplit > 0 ? t.ksplit : -1;
     int want = forced > 0 ? forced : (row_blocks >= 512 ? 1 : (1024 + row_blocks - 1) / (row_blocks > 0 ? row_blocks : 1));
     int ks = 1;
     for (int k = 1; k <= want && k <= 64; k++)
@@ -549,7 +597,7 @@ template <int S>
 static hipError_t launch_sweep_s(hipStream_t st, const SweepParams& p) {
     // 8 rows per wave (4 above 8 bins: the accumulators are RR*S registers), 4 waves per block,
     // non-temporal F loads: measured best on MI355X (profiles/r01/sweep_variants.md)
-    if (S <= 8 && sweep_rr(S) == 8) return launch_cfg<S, 8, 4, 1, true>(st, p);
+    if (S <= 8 && sweep_rr(S, p.tune) == 8) return launch_cfg<S, 8, 4, 1, true>(st, p);
     return launch_cfg<S, 4, 4, 1, true>(st, p);
 }
 
@@ -574,16 +622,24 @@ static hipError_t launch_sweep_mfma(hipStream_t st, const SweepParams& p) {
 __global__ void k_sweep_norows(SweepParams P) {
     if (P.conv_mode != 0 && (P.ctl[1] != 0 || residual_converged(P))) {
         if (threadIdx.x == 0) P.ctl[1] = 1;
+        if (P.n_peers > 0) publish_pass(P);
         return;
     }
-    if (!P.want_sums) return;
-    if ((int)threadIdx.x < P.S) reinterpret_cast<double*>(P.Rout + (size_t)P.rank * P.cstride + (size_t)P.S * P.rpr)[threadIdx.x] = 0.0;
-    if (threadIdx.x == 0) P.ctl[0] = P.ctl[0] + 1;
+    if (P.want_sums) {
+        const size_t at = (size_t)P.rank * P.cstride + (size_t)P.S * P.rpr;
+        if ((int)threadIdx.x < P.S) {
+            reinterpret_cast<double*>(P.Rout + at)[threadIdx.x] = 0.0;
+            for (int q = 0; q < P.n_peers; q++)
+                if (P.peers[q]) reinterpret_cast<double*>(P.peers[q] + at)[threadIdx.x] = 0.0;
+        }
+        if (threadIdx.x == 0) P.ctl[0] = P.ctl[0] + 1;
+    }
+    if (P.n_peers > 0) { __syncthreads(); publish_pass(P); }
 }
 
 hipError_t launch_sweep(hipStream_t st, const SweepParams& p_in) {
     if (p_in.nrows <= 0) {
-        if (p_in.conv_mode == 0 && !p_in.want_sums) return hipSuccess;
+        if (p_in.conv_mode == 0 && !p_in.want_sums && p_in.n_peers == 0) return hipSuccess;
         hipLaunchKernelGGL(k_sweep_norows, dim3(1), dim3(64), 0, st, p_in);
         return hipGetLastError();
     }
@@ -592,16 +648,13 @@ hipError_t launch_sweep(hipStream_t st, const SweepParams& p_in) {
     // (4 MiB per XCD) a skew decorrelates the blocks' column positions, worth +0.5 % at N = 65 536; once it does
     // not (N = 131 072, S = 8: 4 MiB), blocks that run through the columns in step keep the few residual tiles
     // they are all reading in L2: 37 -> 0 is +8 % there and +14 % at N = 262 144 (profiles/r01/sweep_shards.md).
-    static int skew_env = -2, mfma = -1;
-    if (skew_env == -2) { const char* e = getenv("DR_SWEEP_SKEW"); skew_env = e ? atoi(e) : -1; }
     const size_t residual_bytes = sizeof(float) * (size_t)p.world * p.rpr * p.S;
-    const int skew = skew_env >= 0 ? skew_env : (residual_bytes <= ((size_t)5 << 19) ? 37 : 0);
-    if (mfma < 0) { const char* e = getenv("DR_SWEEP_MFMA"); mfma = e ? atoi(e) : 1; }
-    p.skew = skew;
+    p.skew = p.tune.skew >= 0 ? p.tune.skew : (residual_bytes <= ((size_t)5 << 19) ? 37 : 0);
     // column ranges of decreasing size (shares n, n-1, .., 1) when the columns are cut at all: the blocks dispatched last are the
     // shortest, which trims the drain of a small shard's pass (8192 rows of the 64k problem, 4 ranges: 0.348 -> 0.333 ms;
-    // profiles/r02/sweep_shards.md).  DR_SWEEP_TAPER: 0 = equal ranges, t > 0 = shares t + n - y
-    { static int tp = -2; if (tp == -2) { const char* e = getenv("DR_SWEEP_TAPER"); tp = e ? atoi(e) : -1; } p.taper = p.ksplit > 1 ? tp : 0; }
+    // profiles/r02/sweep_shards.md).  SweepTuning::taper: 0 = equal ranges, t > 0 = shares t + n - y
+    p.taper = p.ksplit > 1 ? p.tune.taper : 0;
+    const int mfma = p.tune.mfma;
     if (p.S > 8 && mfma) return launch_sweep_mfma(st, p);
     switch (p.S) {
 #define DR_CASE(n) case n: return launch_sweep_s<n>(st, p);

@@ -1,7 +1,7 @@
 """Static report on the hand-written BVH walks inside k_ff_tiles from the compiler's assembly listing (the Makefile beside this
-file runs it on every build -> ../lib/geom_kernels.walk.txt; tests/test_abi_cpu.py reads it).  Two kernels: <256,false,3> = the
-walk over the sibling-pair records (shipped; its hand-written stretch holds the s_load_dwordx16), <256,false,0> = the threaded
-walk (s_load_dwordx8).  What it guards: SGPR spill reloads (v_readlane / v_writelane) placed by the register allocator right
+file runs it on every build -> ../lib/geom_kernels.walk.txt; tests/test_abi_cpu.py reads it).  Three kernels: <256,false,2> = path
+records + the walk over the sibling-pair records (its hand-written stretches: three streams with s_load_dwordx8, the pair walk
+with s_load_dwordx16), <256,false,3> = the pair walk from the root, <256,false,0> = the threaded walk (s_load_dwordx8).  What it guards: SGPR spill reloads (v_readlane / v_writelane) placed by the register allocator right
 before a walk's entry or right after its exit run once per LEAF visit -- measured +9 % kernel time when a change of the
 surrounding code put 16 there.  (The pair walk's own stack uses v_readlane / v_writelane INSIDE the asm statement: not counted.)"""
 import re
@@ -49,3 +49,5 @@ def report(tag, walk_id, load):
 
 report("", 0, "s_load_dwordx8")
 report("pairs_", 3, "s_load_dwordx16")
+report("paths_", 2, "s_load_dwordx16")          # the pair walk behind the path records
+report("paths_stream_", 2, "s_load_dwordx8")   # the three stretches of path records in front of it

@@ -82,14 +82,57 @@ int dr_shard_rows(int N, int rank, int world, int* row0, int* nrows, int* rows_p
 size_t dr_residual_offset(int i, int s, int S, int rows_per_rank);
 size_t dr_residual_chunk_floats(int S, int rows_per_rank);
 
+/* ---- options -------------------------------------------------------------------- */
+/* Every choice the library makes between equivalent ways of doing the same thing -- which tree, which walk, how a light
+ * pass is cut up, how a group exchanges -- per CONTEXT, settable and readable: none of them changes a result bit (tests
+ * assert that), they change time.  dr_options_defaults fills the struct with the built-in defaults overridden by the
+ * environment variables named below (read there and nowhere else: dr_context_create / dr_group_create call it once);
+ * dr_set_options replaces a context's set (the tree options take effect at the next dr_scene_set_mesh, the pass options
+ * at the next dr_solver_init), dr_get_options reads it back, dr_get_info reports what was actually used. */
+enum { DR_TREE_AUTO = 0, DR_TREE_LBVH = 1, DR_TREE_SAH = 2 };
+enum { DR_WALK_AUTO = 0, DR_WALK_THREADED = 1, DR_WALK_PAIRS = 2, DR_WALK_PATHS = 3 };
+enum { DR_GROUP_EXCHANGE_AUTO = 0, DR_GROUP_EXCHANGE_P2P = 1, DR_GROUP_EXCHANGE_RCCL = 2, DR_GROUP_EXCHANGE_INPASS = 3 };
+typedef struct {
+    int32_t size;               /* sizeof(dr_options) of the caller's header (set by dr_options_defaults; checked by dr_set_options) */
+    /* the tree (dr_scene_set_mesh) */
+    int32_t tree;               /* DR_BVH=lbvh|sah        AUTO: Morton tree below 6 144 patches, SAH topology from there up */
+    int32_t sah_on_host;        /* DR_SAH_HOST=1          1: the SAH topology from the host's reference builder (threads) instead of the device's */
+    int32_t morton_key;         /* DR_BVH_KEY=0|1|2       Morton key variant of the LBVH (geom_kernels.hip, k_morton) */
+    int32_t sah_bins;           /* DR_SAH_BINS            2..128 bins per axis (32) */
+    float   sah_dilate;         /* DR_SAH_DILATE          box growth of the SAH cost in mean patch diagonals (0.5) */
+    int32_t sah_host_threads;   /* DR_SAH_THREADS         threads of the host builder, 0 = up to 8 */
+    /* the assembly (dr_formfactors_assemble) */
+    int32_t walk;               /* DR_WALK=threaded|pairs|paths   AUTO: sibling-pair records, threaded tree when deeper than the walk's stack */
+    int32_t octant_test;        /* DR_OCTANT=0            0: the general node test for every pair (default 1: sign-specialised when a wave's rays share an octant) */
+    int32_t vis_exchange;       /* DR_NO_VIS_EXCHANGE=1 -> 1 never; DR_VIS_EXCHANGE_REHEARSE=1 -> 2 also with a one-rank communicator; 0 auto */
+    int32_t tile_stats;         /* DR_TILE_STATS=1        counted (slow) instantiation of the tile kernel; visits per pair on stderr */
+    int32_t debug_pair_lo, debug_pair_hi, debug_ray;   /* DR_DEBUG_PAIR=lo,hi,ray    (-1: none) */
+    /* the light pass (dr_solver_init) */
+    int32_t sweep_ksplit;       /* DR_SWEEP_KSPLIT        column ranges per row block, 0 = by the shard's size */
+    int32_t sweep_taper;        /* DR_SWEEP_TAPER         -1 auto */
+    int32_t sweep_rows_per_wave;/* DR_SWEEP_RR            0 auto (8; 4 above 8 bins) */
+    int32_t sweep_skew;         /* DR_SWEEP_SKEW          -1 auto */
+    int32_t sweep_mfma;         /* DR_SWEEP_MFMA=0        0: the VALU kernel above 8 bins too (default 1) */
+    int32_t sweep_fenced;       /* DR_SWEEP_FENCED=1      1: the blocks of a pass hand over through agent-scope release / acquire fences
+                                   instead of write-through stores + ticket (the memory-model form; measured 4 % slower) */
+    int32_t no_comm;            /* DR_NO_COMM=1           a world > 1 shard timed on its own: no exchange after a pass */
+    int32_t debug_converge;     /* DR_DEBUG_CONV=1 */
+    /* dr_group */
+    int32_t group_exchange;     /* DR_GROUP_EXCHANGE=p2p|rccl|inpass */
+    int32_t fault_assemble_rank;/* DR_FAULT_ASSEMBLE_RANK tests: the rank whose first assembly launch "fails" (-1: none) */
+} dr_options;
+int dr_options_defaults(dr_options* out);
+int dr_set_options(dr_context* ctx, const dr_options* opt);
+int dr_get_options(dr_context* ctx, dr_options* out);
+
 /* ---- scene --------------------------------------------------------------------- */
 /* Exactly the MeshS / SimpleMesh arrays (vs/MeshS.h:14-20, vs/Defines.h:14-23;
  * handed over today at vs/OptixPrimeFunctionality.cpp:13 and :38-44):
  * vertices 3*V, normals 3*Nn, per-triangle vertex and normal indices 3*N,
  * 0-based.  Builds the per-patch records and the BVH (replaces rtpModelUpdate,
- * vs/OptixPrimeFunctionality.cpp:43-47): a Morton tree on the device, or from
- * 6 144 patches up a SAH topology from the host with bounds and layout on the
- * device (DR_BVH=lbvh|sah overrides; the results do not depend on the tree). */
+ * vs/OptixPrimeFunctionality.cpp:43-47) on the device: a Morton tree, or from
+ * 6 144 patches up a binned-SAH topology (dr_options::tree overrides; the
+ * results do not depend on the tree). */
 int dr_scene_set_mesh(dr_context* ctx, const float* vertices, int V,
                       const float* normals, int Nn,
                       const int32_t* tri_vertex_idx,
@@ -215,7 +258,8 @@ int dr_exchange_import(dr_context* ctx, int src_rank, const float* chunk_in, siz
 /* n contexts, rank r on device_ids[r], rows of F sharded over them; every call below runs on all devices at once
  * (asynchronous launches on one stream per device, one wait at the end).  Distinct devices exchange through RCCL
  * (ncclCommInitAll, grouped calls); the same device listed several times -- a rehearsal of the group on one GPU --
- * or DR_GROUP_EXCHANGE=p2p uses peer copies (hipMemcpyPeerAsync) instead. */
+ * or dr_options::group_exchange = P2P uses peer copies (hipMemcpyPeerAsync) instead; INPASS: every pass stores its new
+ * residual chunk straight into every device's buffer (peer-mapped), no exchange call at all. */
 typedef struct dr_group dr_group;
 int dr_group_create(const int* device_ids, int n_devices, dr_group** out);
 int dr_group_destroy(dr_group* g);
@@ -232,6 +276,8 @@ int dr_group_solver_reset(dr_group* g);
 /* B: all N*S values (every rank writes its rows); R: the gathered residual */
 int dr_group_solver_read(dr_group* g, float* B, float* R);
 int dr_group_synchronize(dr_group* g);
+/* the same options on every context of the group (group_exchange: takes effect at the next dr_group_solver_init) */
+int dr_group_set_options(dr_group* g, const dr_options* opt);
 
 /* ---- measurement ----------------------------------------------------------------- */
 typedef struct {
@@ -246,6 +292,12 @@ typedef struct {
     double sweep_ms_total;    /* their summed hipEvent durations */
     uint64_t blocks_nonzero;  /* with dr_solver_skip_zero_blocks: 32 x 256 blocks of the F shard that hold a non-zero ... */
     uint64_t blocks_total;    /* ... of this many (0 until the first pass after enabling it) */
+    int32_t tree_used;        /* DR_TREE_LBVH / DR_TREE_SAH: what the last dr_scene_set_mesh built */
+    int32_t tree_on_host;     /* 1: its topology came from the host builder */
+    int32_t tree_depth;       /* depth of the written tree */
+    int32_t walk_used;        /* DR_WALK_*: what the last assembly's tile kernel walked */
+    int32_t sweep_ksplit;     /* column ranges per row block of the light pass */
+    int32_t reserved_;
 } dr_info;
 int dr_get_info(dr_context* ctx, dr_info* out);
 /* record a hipEvent pair around every sweep kernel launch (on its own stream) */

@@ -54,6 +54,8 @@ def lib():
         for f in (L.orc_assemble_rows, L.orc_assemble_rows_bvh):
             f.restype = C.c_int
             f.argtypes = [C.POINTER(_Mesh), fp, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, fp, u8p, C.c_int]
+        L.orc_assemble_row_list_bvh.restype = C.c_int
+        L.orc_assemble_row_list_bvh.argtypes = [C.POINTER(_Mesh), fp, C.c_int, C.c_float, C.c_int, ip, C.c_int, fp, u8p, C.c_int]
         L.orc_sweep_rows.argtypes = [C.c_int, C.c_int, fp, C.c_long, C.c_int, C.c_int, fp, ip, fp, fp, fp, C.c_int]
         L.orc_residual_sums.argtypes = [C.c_int, C.c_int, fp, fp]
         L.orc_xyz_fit.argtypes = [C.c_double, fp]
@@ -151,6 +153,19 @@ def assemble_rows(mesh, uv, eps=1e-6, rule=RULE_INTEGRAND, row0=0, nrows=None,
     used = fn(mesh.ref, _p(uv), uv.shape[0], C.c_float(eps), rule, row0, nrows, _p(F),
               _p(vis) if want_vis else None, threads)
     return (F, vis, used) if want_vis else (F, None, used)
+
+
+def assemble_row_list(mesh, uv, rows, eps=1e-6, rule=RULE_INTEGRAND, want_vis=False, threads=0):
+    """F (and ray counts) of an arbitrary list of rows through the oracle's BVH, records and BVH built once."""
+    uv = _f32(uv).reshape(-1, 2)
+    rows = _i32(rows)
+    F = np.empty((rows.shape[0], mesh.N), np.float32)
+    vis = np.empty((rows.shape[0], mesh.N), np.uint8) if want_vis else None
+    used = lib().orc_assemble_row_list_bvh(mesh.ref, _p(uv), uv.shape[0], C.c_float(eps), rule, _p(rows), rows.shape[0], _p(F),
+                                           _p(vis) if want_vis else None, threads)
+    if used < 0:
+        raise ValueError("row outside the mesh")
+    return F, vis, used
 
 
 def sweep_rows(F, M, mat, Rin, B, row0=0, threads=0):

@@ -461,7 +461,7 @@ static int vis_count_bvh(const orc_mesh* m, const cbvh* B, int lo, int hi,
  * CPU-path rule (:311-366): F[row][col] = Fu*V, and when that is > 0 the
  * reverse entry is (A_row*F[row][col])/A_col. */
 static int assemble_impl(const orc_mesh* m, const float* uv, int K, float eps, int rule,
-                         int row0, int nrows, float* F, uint8_t* vis, int threads, int use_bvh) {
+                         int row0, int nrows, float* F, uint8_t* vis, int threads, int use_bvh, const int32_t* row_list) {
     const int N = m->N;
     patch_rec r = rec_build(m);
     tri_rec* T = tris_build(m);
@@ -475,7 +475,7 @@ static int assemble_impl(const orc_mesh* m, const float* uv, int K, float eps, i
 #endif
 #pragma omp parallel for schedule(dynamic, 1) num_threads(used)
     for (int ri = 0; ri < nrows; ri++) {
-        int i = row0 + ri;
+        int i = row_list ? row_list[ri] : row0 + ri;
         for (int j = 0; j < N; j++) {
             float out = 0.0f; uint8_t vc = 255;
             if (i != j) {
@@ -511,11 +511,17 @@ static int assemble_impl(const orc_mesh* m, const float* uv, int K, float eps, i
 
 int orc_assemble_rows(const orc_mesh* m, const float* uv, int K, float eps, int rule,
                       int row0, int nrows, float* F, uint8_t* vis, int threads) {
-    return assemble_impl(m, uv, K, eps, rule, row0, nrows, F, vis, threads, 0);
+    return assemble_impl(m, uv, K, eps, rule, row0, nrows, F, vis, threads, 0, NULL);
 }
 int orc_assemble_rows_bvh(const orc_mesh* m, const float* uv, int K, float eps, int rule,
                           int row0, int nrows, float* F, uint8_t* vis, int threads) {
-    return assemble_impl(m, uv, K, eps, rule, row0, nrows, F, vis, threads, 1);
+    return assemble_impl(m, uv, K, eps, rule, row0, nrows, F, vis, threads, 1, NULL);
+}
+/* the same for an arbitrary list of rows (records and BVH built once for all of them): F / vis hold nrows rows in list order */
+int orc_assemble_row_list_bvh(const orc_mesh* m, const float* uv, int K, float eps, int rule,
+                              const int32_t* rows, int nrows, float* F, uint8_t* vis, int threads) {
+    for (int k = 0; k < nrows; k++) if (rows[k] < 0 || rows[k] >= m->N) return -1;
+    return assemble_impl(m, uv, K, eps, rule, 0, nrows, F, vis, threads, 1, rows);
 }
 
 /* ---- solver -------------------------------------------------------------------

@@ -95,6 +95,9 @@ int orc_assemble_rows(const orc_mesh* m, const float* uv, int K,
 int orc_assemble_rows_bvh(const orc_mesh* m, const float* uv, int K,
                           float origin_eps, int rule, int row0, int nrows,
                           float* F, uint8_t* vis, int threads);
+/* ... for an arbitrary list of rows, the BVH built once (bench.py's CPU baseline: rows spread over the matrix) */
+int orc_assemble_row_list_bvh(const orc_mesh* m, const float* uv, int K, float eps, int rule,
+                              const int32_t* rows, int nrows, float* F, uint8_t* vis, int threads);
 
 /* One light pass for rows [row0,row0+nrows) (Lightning.h:196-226, 342-349,
  * 419-424): G_s[i] = sum_j F[i][j]*R[j][s] (j ascending, fp32);

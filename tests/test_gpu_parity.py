@@ -281,38 +281,59 @@ def test_bvh_invariants():
     assert np.all(b["lo"][0] <= lo) and np.all(b["hi"][0] >= hi)
 
 
-def test_column_split_sweep_matches_oracle(tmp_path):
+@pytest.mark.parametrize("fenced", [0, 1])
+def test_column_split_sweep_matches_oracle(fenced):
     """small row shards cut the columns into ranges (k_sweep<..., SPLIT>: the last range of a row block adds the partial sums);
-    forced here through DR_SWEEP_KSPLIT in a child process (the knob is read once per process)"""
-    import subprocess
-    import sys
-    code = r'''
-import sys, numpy as np
-sys.path.insert(0, %r)
-from daisyriot_amd import api, scenes
-from oracle import binding as ob
-rs = np.random.RandomState(11)
-for S in (3, 8, 12):
-    sc = scenes.cornell_box(1000, S=S)
-    N = sc.N
-    F = (rs.random_sample((N, N)) * (rs.random_sample((N, N)) < 0.4) / N).astype(np.float32)
-    E = rs.random_sample((N, S)).astype(np.float32)
+    forced here through the context's options (dr_options::sweep_ksplit) -- with the hand-offs between the blocks of a pass in
+    their shipped form (write-through stores + ticket) and in the memory-model form (release / acquire fences): same bits"""
+    rs = np.random.RandomState(11)
+    for S in (3, 8, 12):
+        sc = scenes.cornell_box(1000, S=S)
+        N = sc.N
+        F = (rs.random_sample((N, N)) * (rs.random_sample((N, N)) < 0.4) / N).astype(np.float32)
+        E = rs.random_sample((N, S)).astype(np.float32)
+        got = {}
+        for fz in sorted({0, fenced}):
+            with api.Context(0) as c:
+                o = c.set_options(sweep_ksplit=4, sweep_fenced=fz)
+                assert o.sweep_ksplit == 4 and c.options().sweep_fenced == fz
+                c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+                c.load_rows(0, F)
+                c.solver_init(E, sc.M, sc.mat_of_patch)
+                assert c.info().sweep_ksplit == 4
+                c.step(3)
+                got[fz] = c.read()
+        Bg, Rg = got[fenced]
+        assert np.array_equal(_bits(got[0][0]), _bits(Bg)) and np.array_equal(_bits(got[0][1]), _bits(Rg))
+        R, B = E.copy(), E.copy()
+        for _ in range(3):
+            R = ob.sweep_rows(F, sc.M, sc.mat_of_patch, R, B)
+        assert (np.abs(Rg - R) / np.abs(R).max(axis=0)).max() < 2e-5, S
+        assert (np.abs(Bg - B) / np.abs(B).max(axis=0)).max() < 2e-5, S
+
+
+def test_options_round_trip_and_validation():
+    """dr_options: what is set is what is read back; nonsense is refused; the pass layout cannot change under a live solver"""
+    d = api.options_defaults()
     with api.Context(0) as c:
+        assert c.options().as_dict() == d.as_dict()
+        o = c.set_options(tree=api.TREE_LBVH, walk=api.WALK_THREADED, sah_bins=16, sweep_taper=2)
+        assert (o.tree, o.walk, o.sah_bins, o.sweep_taper) == (api.TREE_LBVH, api.WALK_THREADED, 16, 2)
+        assert c.options().as_dict() == o.as_dict()
+        for bad in (dict(tree=7), dict(walk=-1), dict(sah_bins=1), dict(sweep_ksplit=65), dict(sweep_rows_per_wave=3),
+                    dict(group_exchange=9), dict(sah_dilate=float("nan"))):
+            with pytest.raises(api.DaisyRiotError):
+                c.set_options(**bad)
+        assert c.options().as_dict() == o.as_dict()             # a refused set changes nothing
+        sc = scenes.cornell_box(300, S=3)
         c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
-        c.load_rows(0, F)
-        c.solver_init(E, sc.M, sc.mat_of_patch)
-        c.step(3)
-        Bg, Rg = c.read()
-    R, B = E.copy(), E.copy()
-    for _ in range(3):
-        R = ob.sweep_rows(F, sc.M, sc.mat_of_patch, R, B)
-    assert (np.abs(Rg - R) / np.abs(R).max(axis=0)).max() < 2e-5, S
-    assert (np.abs(Bg - B) / np.abs(B).max(axis=0)).max() < 2e-5, S
-print("SPLIT_OK")
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DR_SWEEP_KSPLIT="4")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert "SPLIT_OK" in r.stdout, r.stderr[-2000:]
+        i = c.info()
+        assert i.tree_used == api.TREE_LBVH and i.tree_depth > 3
+        c.integrand_only()
+        c.solver_init(sc.emission(7.0), sc.M, sc.mat_of_patch)
+        with pytest.raises(api.DaisyRiotError, match="cannot change under an initialised solver"):
+            c.set_options(sweep_ksplit=2)
+        c.set_options(sweep_taper=0)                             # (not a layout option: allowed)
 
 
 def test_rccl_binding_single_rank(uv50):
@@ -691,10 +712,14 @@ def test_work_on_the_callers_stream(uv50):
     assert np.array_equal(_bits(B1), _bits(B0)) and np.array_equal(_bits(R1), _bits(R0))
 
 
-@pytest.mark.parametrize("world,S,n", [(2, 8, 700), (3, 3, 2500), (4, 9, 1300)])
-def test_group_one_process_several_ranks(world, S, n, uv50):
-    """dr_group: one process, `world` ranks (here all on GPU 0: the one-GPU rehearsal, exchange by peer copies) -- assembly
-    with ray-count exchange, passes and converge give the single-context results"""
+@pytest.mark.parametrize("exchange", ["p2p", "inpass"])
+@pytest.mark.parametrize("world,S,n", [(2, 8, 700), (3, 3, 2500), (4, 9, 1300), (3, 3, 400)])
+def test_group_one_process_several_ranks(world, S, n, exchange, uv50):
+    """dr_group: one process, `world` ranks (here all on GPU 0: the one-GPU rehearsal) -- assembly with ray-count exchange,
+    passes and converge give the single-context results.  Exchange of the residual by peer copies behind events (p2p), or
+    IN the pass (dr_options::group_exchange = INPASS): the pass kernel stores its chunk and its sums into every rank's buffer
+    and publishes its number, the next pass starts behind a one-thread gate kernel -- no copy, no collective, no event; same
+    bits either way.  (3, 3, 400) leaves the last rank without rows."""
     sc = scenes.cornell_box(n, S=S, fluorescent=(S >= 8))
     E = sc.emission(7.0)
     with _ctx(sc) as c:
@@ -710,6 +735,8 @@ def test_group_one_process_several_ranks(world, S, n, uv50):
         Bc1, _ = c.read()
     with api.Group([0] * world) as g:
         assert not g.uses_rccl()
+        if exchange == "inpass":
+            assert g.set_options(group_exchange=api.GROUP_EXCHANGE_INPASS).group_exchange == api.GROUP_EXCHANGE_INPASS
         g.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
         g.assemble(uv50, keep_visibility=True)
         assert sum(c.info().pairs_traced for c in g.ranks) == traced_once
@@ -728,15 +755,22 @@ def test_group_one_process_several_ranks(world, S, n, uv50):
             assert np.array_equal(_bits(Rc), _bits(R))
         g.reset()
         assert g.converge(thr, per_bin=per_bin, max_iters=300) == it1
-        Bc, _ = g.read()
+        Bc, Rc = g.read()
         assert np.allclose(Bc, Bc1, rtol=2e-6, atol=1e-12)
+        KEEP[(world, S, n, exchange)] = (_bits(B).copy(), _bits(R).copy(), _bits(Bc).copy(), _bits(Rc).copy())
+    other = KEEP.get((world, S, n, "p2p" if exchange == "inpass" else "inpass"))
+    if other is not None:                                     # the two exchanges: bit-identical B and R
+        assert all(np.array_equal(a, b) for a, b in zip(other, KEEP[(world, S, n, exchange)]))
 
 
-def test_sah_tree_on_degenerate_layouts(uv50, monkeypatch):
-    """The host's SAH build on inputs that defeat binning: triangles strung along a line at exponentially growing distances (every
+KEEP = {}
+
+
+@pytest.mark.parametrize("on_host", [0, 1])
+def test_sah_tree_on_degenerate_layouts(uv50, on_host):
+    """The SAH build (on the device, and the host's reference builder) on inputs that defeat binning: triangles strung along a line at exponentially growing distances (every
     cut is lopsided) and a pile of coincident triangles (all centroids in one bin) -- the median fallback keeps the tree
     logarithmic, and the ray counts and F still equal the brute-force oracle's."""
-    monkeypatch.setenv("DR_BVH", "sah")
     rs = np.random.RandomState(11)
     base = (rs.random_sample((1, 3, 3)) - 0.5).astype(np.float64)
     line = np.concatenate([base + np.array([[[1.35 ** k, 0.0, 0.3 * (k % 3)]]]) for k in range(60)])
@@ -749,53 +783,86 @@ def test_sah_tree_on_degenerate_layouts(uv50, monkeypatch):
     nrm = rs.normal(size=(8, 3)).astype(np.float32)
     tn = rs.randint(0, 8, size=(n, 3)).astype(np.int32)
     with api.Context(0) as c:
+        c.set_options(tree=api.TREE_SAH, sah_on_host=on_host)
         c.set_mesh(v, nrm, tv, tn)
+        assert c.info().tree_depth < 40                     # logarithmic whatever the layout
         c.assemble(uv50, keep_visibility=True)
         vis, F = c.read_visibility(0, n), c.read_rows(0, n)
     Fo, viso, _ = ob.assemble_rows(ob.Mesh(v, nrm, tv, tn), uv50, bvh=False)
     assert np.array_equal(vis, viso) and np.array_equal(_bits(F), _bits(Fo))
 
 
-def test_both_trees_give_the_same_matrix_at_16k(uv50, monkeypatch):
-    """The tree only decides how many nodes a walk visits, never what is hit: the Morton tree built on the device and the SAH
-    topology built on the host (the default at this size) give the same ray counts and the same F, bit for bit, on every row
-    of a 16 384-patch scene (hashes of all rows + a few rows in full)."""
+def test_device_sah_tree_is_the_hosts_tree():
+    """the SAH topology built on the device (level by level, one workgroup per open node) against the host's reference builder
+    on the same scene: the same algorithm in the same float expressions, so -- up to the order inside a leaf pair and tie
+    cases -- the same tree: equal node counts and depths within one, and a summed node area (what a walk pays for) within 0.5 %"""
+    for n in (7000, 16384):
+        sc = scenes.cornell_box(n, S=3)
+        got = {}
+        for on_host in (0, 1):
+            with api.Context(0) as c:
+                c.set_options(tree=api.TREE_SAH, sah_on_host=on_host)
+                c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+                i = c.info()
+                assert i.tree_used == api.TREE_SAH and i.tree_on_host == on_host
+                b = c.read_bvh()
+                ext = np.maximum(b["hi"].astype(np.float64) - b["lo"], 0.0)
+                area = ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 2] * ext[:, 0]
+                # every patch exactly once in the leaves (leaf code = first * 8 + count - 1 [+ 4])
+                leaves = b["tri"][b["tri"] >= 0]
+                cover = np.zeros(n, np.int32)
+                for code in leaves:
+                    cover[(code >> 3):(code >> 3) + (code & 3) + 1] += 1
+                assert (cover == 1).all()
+                got[on_host] = (len(b), i.tree_depth, area.sum(), i.last_bvh_ms)
+        assert abs(got[0][0] - got[1][0]) <= 0.002 * got[1][0], got
+        assert abs(got[0][1] - got[1][1]) <= 1, got
+        assert abs(got[0][2] - got[1][2]) <= 0.005 * got[1][2], got
+
+
+def test_all_trees_give_the_same_matrix_at_16k(uv50):
+    """The tree only decides how many nodes a walk visits, never what is hit: the Morton tree, the SAH topology built on the
+    device (the default at this size) and the one from the host's reference builder give the same ray counts and the same F,
+    bit for bit, on every row of a 16 384-patch scene (hashes of all rows)."""
     import hashlib
     sc = scenes.cornell_box(16384, S=8)
     got = {}
-    for tree in ("lbvh", "sah"):
-        monkeypatch.setenv("DR_BVH", tree)
-        with _ctx(sc) as c:
+    for tree, opts in (("lbvh", dict(tree=api.TREE_LBVH)), ("sah", dict(tree=api.TREE_SAH)), ("sah-host", dict(tree=api.TREE_SAH, sah_on_host=1))):
+        with api.Context(0) as c:
+            c.set_options(**opts)
+            c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
             c.assemble(uv50, keep_visibility=True)
             hF, hV = hashlib.sha256(), hashlib.sha256()
             for r0 in range(0, 16384, 2048):
                 hF.update(_bits(c.read_rows(r0, 2048)).tobytes())
                 hV.update(c.read_visibility(r0, 2048).tobytes())
             got[tree] = (hF.hexdigest(), hV.hexdigest(), c.info().pairs_traced)
-    assert got["lbvh"] == got["sah"]
+    assert got["lbvh"] == got["sah"] == got["sah-host"]
 
 
-@pytest.mark.parametrize("mode", ["shaft", "paths", "general-node-test", "sah-tree", "morton-tree", "sah-tree+paths"])
-def test_alternative_walks_are_exact(mode, uv50, monkeypatch):
-    """The walks that are built, exact and not shipped as the default (profiles/r02/assembly_notes.md) -- DR_SHAFT=1: tile-pair
-    shaft lists; DR_PATHS=1: per-patch path records; DR_OCTANT=0: the general node test for every pair -- and the two trees
-    (DR_BVH=sah: topology from the host's binned SAH, DR_BVH=lbvh: the device's Morton tree) give the same ray
-    counts and F as the brute-force oracle: on a soup far from the origin, on the Cornell box, and with an origin offset that
-    throws rays out of their tile's box (shaft lists: those pairs walk from the root)"""
-    if mode == "shaft":
-        monkeypatch.setenv("DR_SHAFT", "1")
-    elif mode == "paths":
-        monkeypatch.setenv("DR_PATHS", "1")
-    elif mode == "general-node-test":
-        monkeypatch.setenv("DR_OCTANT", "0")
-    elif mode == "sah-tree":          # the host's SAH topology (the default from 6 144 patches up) on these small scenes
-        monkeypatch.setenv("DR_BVH", "sah")
-    elif mode == "morton-tree":
-        monkeypatch.setenv("DR_BVH", "lbvh")
-    else:
-        monkeypatch.setenv("DR_BVH", "sah"); monkeypatch.setenv("DR_PATHS", "1")
-    for mn in (("8", "128") if mode == "shaft" else ("128",)):
-        monkeypatch.setenv("DR_SHAFT_MIN", mn)
+ALT_MODES = {
+    "threaded-walk": dict(walk=api.WALK_THREADED),
+    "pair-walk": dict(walk=api.WALK_PAIRS),
+    "path-records": dict(walk=api.WALK_PATHS),
+    "general-node-test": dict(octant_test=0),
+    "general-node-test+threaded": dict(octant_test=0, walk=api.WALK_THREADED),
+    "sah-tree": dict(tree=api.TREE_SAH),
+    "sah-tree-from-host": dict(tree=api.TREE_SAH, sah_on_host=1),
+    "morton-tree": dict(tree=api.TREE_LBVH),
+    "sah-tree+path-records": dict(tree=api.TREE_SAH, walk=api.WALK_PATHS),
+    "morton-tree+threaded": dict(tree=api.TREE_LBVH, walk=api.WALK_THREADED),
+}
+
+
+@pytest.mark.parametrize("mode", sorted(ALT_MODES))
+def test_alternative_walks_are_exact(mode, uv50):
+    """Every tree and every walk the options offer (dr_options: walk = threaded tree | sibling-pair records | path records in
+    front of the pair walk; octant_test = 0: the general node test for every pair; tree = Morton on the device | binned SAH
+    on the device | binned SAH from the host's reference builder) gives the same ray counts and F as the brute-force
+    oracle: on a soup far from the origin, on the Cornell box, and with an origin offset that throws rays far from their
+    patches.  The context reports what it really used."""
+    opts = ALT_MODES[mode]
+    if True:
         rs = np.random.RandomState(5)
         n = 300
         c0 = rs.random_sample((n, 1, 3)) * 2 - 1
@@ -806,13 +873,21 @@ def test_alternative_walks_are_exact(mode, uv50, monkeypatch):
         tn = rs.randint(0, 16, size=(n, 3)).astype(np.int32)
         for eps in (api.ORIGIN_EPS, 0.3):
             with api.Context(0) as c:
+                c.set_options(**opts)
                 c.set_mesh(v, nrm, tv, tn)
                 c.assemble(uv50, eps=eps, keep_visibility=True)
                 vis, F = c.read_visibility(0, n), c.read_rows(0, n)
+                i = c.info()
+            if "walk" in opts:
+                assert i.walk_used == opts["walk"]
+            if "tree" in opts:
+                assert i.tree_used == opts["tree"] and i.tree_on_host == opts.get("sah_on_host", 0)
             Fo, viso, _ = ob.assemble_rows(ob.Mesh(v, nrm, tv, tn), uv50, eps=eps, bvh=False)
             assert np.array_equal(vis, viso) and np.array_equal(_bits(F), _bits(Fo))
         sc = scenes.cornell_box(1500, S=3)
-        with _ctx(sc) as c:
+        with api.Context(0) as c:
+            c.set_options(**opts)
+            c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
             c.assemble(uv50, keep_visibility=True)
             vis, F = c.read_visibility(0, sc.N), c.read_rows(0, sc.N)
         Fo, viso, _ = ob.assemble_rows(ob.Mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n), uv50, bvh=True)
