@@ -199,43 +199,106 @@ __global__ void k_hierarchy(int N, const unsigned long long* __restrict__ keys, 
     if (i == 0) parent[0] = -1;
 }
 
-__global__ void k_refit(int N, const TriRec* __restrict__ tri, const int* __restrict__ sorted_tri,
-                        const int* __restrict__ left, const int* __restrict__ right,
-                        const int* __restrict__ first, const int* __restrict__ last,
-                        const int* __restrict__ parent, int* __restrict__ flags,
-                        float* __restrict__ box /* (2N-1) x 6 */, int* __restrict__ esize /* 2N-1 */,
-                        TriRec* __restrict__ tri_sorted, int* __restrict__ pos /* patch -> Morton position */) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= N) return;
-    const TriRec T = tri[sorted_tri[k]];
-    tri_sorted[k] = T;
-    pos[sorted_tri[k]] = k;
-    float lo[3], hi[3];
-    tri_bounds(T, lo, hi);
-    int id = N - 1 + k;
-    float* b = box + 6 * (size_t)id;
-    // node boxes are plain unions of the triangles' (already padded) boxes: the fp32 slab test is
-    // monotone under box enlargement, so culling by them is exact
-    for (int a = 0; a < 3; a++) { b[a] = lo[a]; b[3 + a] = hi[a]; }
-    esize[id] = 1;
-    int es = 1;                                 // nodes this subtree contributes to the output
-    int p = (N > 1) ? parent[id] : -1;
-    while (p >= 0) {
-        __threadfence();                       // publish this subtree's box and size (agent scope)
-        int old = atomicAdd(&flags[p], 1);
-        if (old == 0) return;                  // the sibling's thread continues upwards
-        __threadfence();                       // acquire the sibling's box and size
-        int sib = (left[p] == id) ? right[p] : left[p];
-        const volatile float* sb = box + 6 * (size_t)sib;
-        for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], sb[a]); hi[a] = fmaxf(hi[a], sb[3 + a]); }
-        float* pb = box + 6 * (size_t)p;
-        for (int a = 0; a < 3; a++) { pb[a] = lo[a]; pb[3 + a] = hi[a]; }
-        const int sib_es = ((const volatile int*)esize)[sib];
-        es = (last[p] - first[p] + 1 <= LEAF_MAX) ? 1 : 1 + es + sib_es;
-        esize[p] = es;
-        id = p;
-        p = parent[p];
+// Bounds and written sizes of all nodes WITHOUT a bottom-up pass.  Every node covers a stretch [first, last] of the leaf order,
+// so its box is a range union over the leaves' boxes and the number of nodes its subtree contributes to the output a range
+// count -- both answered from small tables, every node on its own thread, no atomics, no fences.  (Round 2's k_refit climbed
+// from every leaf with an arrival counter per node and two agent-scope fences per level: 380 us at 64k patches, a third of
+// the build, because a fence writes back and invalidates an XCD's L2.)  Tables: per leaf the unions of its 64-leaf block up to
+// it and from it on (pre64 / suf64), the blocks' boxes (blk) and the same one level up for blocks of 64 blocks (4096 leaves).
+// Node boxes are plain unions of the triangles' (already padded) gate boxes -- the fp32 slab test is monotone under box
+// enlargement, so culling by them is exact -- and min / max are order-free: the same floats as any other order gives.
+struct Box6 { float lo[3], hi[3]; };
+__device__ __forceinline__ Box6 box_empty() { return Box6{ { INFINITY, INFINITY, INFINITY }, { -INFINITY, -INFINITY, -INFINITY } }; }
+__device__ __forceinline__ Box6 box_join(Box6 a, const Box6& b) {
+    for (int x = 0; x < 3; x++) { a.lo[x] = fminf(a.lo[x], b.lo[x]); a.hi[x] = fmaxf(a.hi[x], b.hi[x]); }
+    return a;
+}
+__device__ __forceinline__ Box6 box_ld(const float* p) { return Box6{ { p[0], p[1], p[2] }, { p[3], p[4], p[5] } }; }
+__device__ __forceinline__ void box_st(float* p, const Box6& b) { for (int x = 0; x < 3; x++) { p[x] = b.lo[x]; p[3 + x] = b.hi[x]; } }
+
+// inclusive unions over the lanes of a wave: up to and including this lane (pre), from this lane on (suf)
+__device__ __forceinline__ void wave_box_scans(const Box6& mine, int lane, Box6& pre, Box6& suf) {
+    pre = mine; suf = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        Box6 u, d;
+        for (int x = 0; x < 3; x++) {
+            u.lo[x] = __shfl_up(pre.lo[x], o); u.hi[x] = __shfl_up(pre.hi[x], o);
+            d.lo[x] = __shfl_down(suf.lo[x], o); d.hi[x] = __shfl_down(suf.hi[x], o);
+        }
+        if (lane >= o) pre = box_join(pre, u);
+        if (lane + o < 64) suf = box_join(suf, d);
     }
+}
+
+__global__ __launch_bounds__(256) void k_refit_leaves(int N, const TriRec* __restrict__ tri, const int* __restrict__ sorted_tri, TriRec* __restrict__ tri_sorted,
+                                                      int* __restrict__ pos, float* __restrict__ box /* (2N-1) x 6 */, int* __restrict__ esize,
+                                                      float* __restrict__ pre64, float* __restrict__ suf64, float* __restrict__ blk) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    Box6 mine = box_empty();
+    if (k < N) {
+        const TriRec T = tri[sorted_tri[k]];
+        tri_sorted[k] = T;
+        pos[sorted_tri[k]] = k;
+        for (int x = 0; x < 3; x++) { mine.lo[x] = T.lo[x]; mine.hi[x] = T.hi[x]; }
+        box_st(box + 6 * (size_t)(N - 1 + k), mine);
+        esize[N - 1 + k] = 1;
+    }
+    Box6 pre, suf;
+    wave_box_scans(mine, lane, pre, suf);
+    if (k < N) { box_st(pre64 + 6 * (size_t)k, pre); box_st(suf64 + 6 * (size_t)k, suf); }
+    if (lane == 63 && k - 63 < N) box_st(blk + 6 * (size_t)(k >> 6), pre);       // (lanes past the end carry empty boxes)
+}
+
+// the same one level up: entries = the 64-leaf blocks' boxes
+__global__ __launch_bounds__(256) void k_refit_blocks(int nblk, const float* __restrict__ blk, float* __restrict__ pre_b, float* __restrict__ suf_b,
+                                                      float* __restrict__ sblk) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const Box6 mine = k < nblk ? box_ld(blk + 6 * (size_t)k) : box_empty();
+    Box6 pre, suf;
+    wave_box_scans(mine, lane, pre, suf);
+    if (k < nblk) { box_st(pre_b + 6 * (size_t)k, pre); box_st(suf_b + 6 * (size_t)k, suf); }
+    if (lane == 63 && k - 63 < nblk) box_st(sblk + 6 * (size_t)(k >> 6), pre);
+}
+
+// w[k] = 1 where a WRITTEN leaf starts: a node of at most LEAF_MAX triangles under a parent of more (its subtree is collapsed)
+__global__ void k_refit_marks(int N, const int* __restrict__ first, const int* __restrict__ last, const int* __restrict__ parent, int* __restrict__ w) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 2 * N - 1) return;
+    const bool internal = id < N - 1;
+    const int f = internal ? first[id] : id - (N - 1);
+    const int cnt = internal ? last[id] - first[id] + 1 : 1;
+    if (cnt > LEAF_MAX) return;
+    const int p = N > 1 ? parent[id] : -1;
+    if (p < 0 || last[p] - first[p] + 1 > LEAF_MAX) w[f] = 1;
+}
+
+__global__ void k_refit_nodes(int N, const int* __restrict__ first, const int* __restrict__ last, const int* __restrict__ wsum /* exclusive, N + 1 */,
+                              const float* __restrict__ pre64, const float* __restrict__ suf64, const float* __restrict__ blk,
+                              const float* __restrict__ pre_b, const float* __restrict__ suf_b, const float* __restrict__ sblk,
+                              float* __restrict__ box, int* __restrict__ esize) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N - 1) return;
+    const int f = first[i], l = last[i];
+    const int bf = f >> 6, bl = l >> 6;
+    Box6 r;
+    if (bf == bl) {
+        r = box_empty();
+        for (int k = f; k <= l; k++) r = box_join(r, box_ld(box + 6 * (size_t)(N - 1 + k)));
+    } else {
+        r = box_join(box_ld(suf64 + 6 * (size_t)f), box_ld(pre64 + 6 * (size_t)l));
+        const int m0 = bf + 1, m1 = bl - 1;                      // whole blocks in between
+        if (m0 <= m1) {
+            const int sf = m0 >> 6, sl = m1 >> 6;
+            if (sf == sl) { for (int q = m0; q <= m1; q++) r = box_join(r, box_ld(blk + 6 * (size_t)q)); }
+            else {
+                r = box_join(r, box_join(box_ld(suf_b + 6 * (size_t)m0), box_ld(pre_b + 6 * (size_t)m1)));
+                for (int q = sf + 1; q <= sl - 1; q++) r = box_join(r, box_ld(sblk + 6 * (size_t)q));
+            }
+        }
+    }
+    box_st(box + 6 * (size_t)i, r);
+    // nodes this subtree contributes to the output: one if it is collapsed into a leaf, else a full binary tree over its written leaves
+    esize[i] = (l - f + 1 <= LEAF_MAX) ? 1 : 2 * (wsum[l + 1] - wsum[f]) - 1;
 }
 
 // A node is written iff no proper ancestor is collapsed; it is a leaf iff it covers at most
@@ -380,18 +443,20 @@ __global__ void k_pad_tris(int N, TriRec* __restrict__ tri_sorted) {
 // Any tree gives bit-identical results; this one is the host's up to the order inside a leaf pair and tie cases.
 // ---------------------------------------------------------------------------------------
 struct SahJob { int b, e, id; };
-constexpr int SAH_NT = 256;
+constexpr int SAH_BIG = 4096;         // nodes of this many patches or more are split by 1024-thread workgroups, the others by 256-thread ones
 constexpr int SAH_NBMAX = 128;
 
 __device__ __forceinline__ int f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
-// centroids of the gate boxes (the host's expression) and the deterministic mean of the boxes' diagonals (one block)
-__global__ __launch_bounds__(1024) void k_sah_prepare(int N, const TriRec* __restrict__ tri, float* __restrict__ cen, double* __restrict__ diag_mean,
-                                                      int* __restrict__ order) {
-    __shared__ double sh[1024];
+// centroids of the gate boxes (the host's expression), the identity order, and the mean of the boxes' diagonals: per block a
+// fixed subset of the patches summed in a fixed order (then k_sah_diag_mean over the blocks' sums): the same value every run
+constexpr int SAH_PREP_BLOCKS = 128;
+__global__ __launch_bounds__(256) void k_sah_prepare(int N, const TriRec* __restrict__ tri, float* __restrict__ cen, double* __restrict__ diag_part,
+                                                     int* __restrict__ order) {
+    __shared__ double sh[256];
     double a = 0.0;
-    for (int i = threadIdx.x; i < N; i += 1024) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += SAH_PREP_BLOCKS * 256) {
         const TriRec T = tri[i];
         double q = 0.0;
         for (int x = 0; x < 3; x++) {
@@ -404,11 +469,17 @@ __global__ __launch_bounds__(1024) void k_sah_prepare(int N, const TriRec* __res
     }
     sh[threadIdx.x] = a;
     __syncthreads();
-    for (int w = 512; w >= 1; w >>= 1) {
+    for (int w = 128; w >= 1; w >>= 1) {
         if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) diag_mean[0] = sh[0] / (double)N;
+    if (threadIdx.x == 0) diag_part[1 + blockIdx.x] = sh[0];
+}
+__global__ void k_sah_diag_mean(int N, double* __restrict__ diag_part) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double a = 0.0;
+    for (int k = 0; k < SAH_PREP_BLOCKS; k++) a += diag_part[1 + k];
+    diag_part[0] = a / (double)N;
 }
 
 __device__ __forceinline__ float sah_area(const float lo[3], const float hi[3], float grow) {
@@ -416,7 +487,8 @@ __device__ __forceinline__ float sah_area(const float lo[3], const float hi[3], 
     return dx * dy + dy * dz + dz * dx;
 }
 
-// exclusive scan of one flag per thread over the block (SAH_NT threads); total in *tot
+// exclusive scan of one flag per thread over the block (SAH_NT threads); total in tot
+template <int SAH_NT>
 __device__ __forceinline__ int block_rank(bool flag, int* sWave /* SAH_NT / 64 + 1 */, int& tot) {
     const unsigned long long m = __ballot(flag);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -429,11 +501,328 @@ __device__ __forceinline__ int block_rank(bool flag, int* sWave /* SAH_NT / 64 +
     return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 
+// BIG nodes (SAH_BIG patches or more): their two gathering passes -- centroid bounds, bins -- run on many workgroups, one per
+// SAH_CHUNK patches of the node's stretch (a single workgroup binning 64k patches spends its time in same-address LDS atomics:
+// 235 us per level measured), each with its own bins in LDS, merged into the node's bins in global memory (integer atomics on
+// the order-preserving keys, so the merged bins are the same whatever the order); the node's own workgroup then starts from
+// those (k_sah_level<1024, true>).  Block -> (job, chunk): a scan over the level's few big jobs.
+constexpr int SAH_CHUNK = 2048;
+constexpr int SAH_GB = 3 * SAH_NBMAX * 7;        // ints of one big node's merged bins: per axis and bin: count, lo[3], hi[3]
+
+__device__ __forceinline__ bool sah_find_chunk(const SahJob* __restrict__ q, int njobs, int block, SahJob& J, int& j_out, int& c0, int& c1) {
+    int acc = 0;
+    for (int j = 0; j < njobs; j++) {
+        const SahJob X = q[j];
+        const int nch = (X.e - X.b + SAH_CHUNK - 1) / SAH_CHUNK;
+        if (block < acc + nch) { J = X; j_out = j; c0 = X.b + (block - acc) * SAH_CHUNK; c1 = min(X.e, c0 + SAH_CHUNK); return true; }
+        acc += nch;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void k_sah_big_bounds(const float* __restrict__ cen, const SahJob* __restrict__ qin, const int* __restrict__ n_in,
+                                                        const int* __restrict__ src, int* __restrict__ gcb /* [job][6] ordered keys */) {
+    SahJob J; int j, c0, c1;
+    if (!sah_find_chunk(qin, *n_in, blockIdx.x, J, j, c0, c1)) return;
+    int lo3[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi3[3] = { (int)0x80000000, (int)0x80000000, (int)0x80000000 };
+    for (int k = c0 + threadIdx.x; k < c1; k += 256) {
+        const int t = src[k];
+        for (int a = 0; a < 3; a++) { const int o = f2ord(cen[3 * (size_t)t + a]); lo3[a] = min(lo3[a], o); hi3[a] = max(hi3[a], o); }
+    }
+    for (int a = 0; a < 3; a++) {
+        for (int o = 32; o >= 1; o >>= 1) { lo3[a] = min(lo3[a], __shfl_xor(lo3[a], o)); hi3[a] = max(hi3[a], __shfl_xor(hi3[a], o)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&gcb[6 * j + a], lo3[a]); atomicMax(&gcb[6 * j + 3 + a], hi3[a]); }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sah_big_bins(const TriRec* __restrict__ tri, const float* __restrict__ cen, int NB, const SahJob* __restrict__ qin,
+                                                      const int* __restrict__ n_in, const int* __restrict__ src, const int* __restrict__ gcb,
+                                                      int* __restrict__ gbins /* [job][SAH_GB] */) {
+    __shared__ int sB[SAH_GB];
+    SahJob J; int j, c0, c1;
+    if (!sah_find_chunk(qin, *n_in, blockIdx.x, J, j, c0, c1)) return;
+    for (int x = threadIdx.x; x < 3 * NB; x += 256) {
+        const int a = x / NB, q = x % NB;
+        int* B = sB + (a * SAH_NBMAX + q) * 7;
+        B[0] = 0;
+        for (int d = 0; d < 3; d++) { B[1 + d] = 0x7fffffff; B[4 + d] = (int)0x80000000; }
+    }
+    __syncthreads();
+    float clo[3], scale[3];
+    bool valid[3];
+    for (int a = 0; a < 3; a++) {
+        clo[a] = ord2f(gcb[6 * j + a]);
+        const float ext = ord2f(gcb[6 * j + 3 + a]) - clo[a];
+        scale[a] = (float)NB / ext;
+        valid[a] = (ext > 0.0f) && isfinite(scale[a]);
+    }
+    for (int k = c0 + threadIdx.x; k < c1; k += 256) {
+        const int t = src[k];
+        const TriRec T = tri[t];
+        for (int a = 0; a < 3; a++) {
+            if (!valid[a]) continue;
+            const int q = max(0, min(NB - 1, (int)((cen[3 * (size_t)t + a] - clo[a]) * scale[a])));
+            int* B = sB + (a * SAH_NBMAX + q) * 7;
+            atomicAdd(&B[0], 1);
+            for (int d = 0; d < 3; d++) { atomicMin(&B[1 + d], f2ord(T.lo[d])); atomicMax(&B[4 + d], f2ord(T.hi[d])); }
+        }
+    }
+    __syncthreads();
+    int* G = gbins + (size_t)j * SAH_GB;
+    for (int x = threadIdx.x; x < 3 * NB; x += 256) {
+        const int a = x / NB, q = x % NB;
+        const int* B = sB + (a * SAH_NBMAX + q) * 7;
+        if (B[0] == 0) continue;
+        int* Gq = G + (a * SAH_NBMAX + q) * 7;
+        atomicAdd(&Gq[0], B[0]);
+        for (int d = 0; d < 3; d++) { atomicMin(&Gq[1 + d], B[1 + d]); atomicMax(&Gq[4 + d], B[4 + d]); }
+    }
+}
+
+// the merged bounds and bins back to "empty" for the next level's big nodes
+__global__ void k_sah_big_reset(int n_jobs_cap, int* __restrict__ gcb, int* __restrict__ gbins) {
+    const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < (size_t)n_jobs_cap * 6) gcb[x] = (x % 6) < 3 ? 0x7fffffff : (int)0x80000000;
+    if (x < (size_t)n_jobs_cap * SAH_GB) { const int f = (int)(x % 7); gbins[x] = f == 0 ? 0 : (f < 4 ? 0x7fffffff : (int)0x80000000); }
+}
+
+// A big node's patches into the other order buffer, a workgroup per chunk: the node's workgroup has published the split
+// (gsel[job]: mode 0 plane / 1 median / 2 halves as they lie, axis, bin or key, patches on the left, how many of the keys equal
+// to the median go left, then three cursors); a chunk counts its patches for either side, reserves that many places on each with
+// one atomic per side and writes.  (Which of the equal keys go left, and the order inside a side, depend on the order the chunks
+// arrive in: any choice is a valid tree, and the results do not depend on the tree.)
+__global__ __launch_bounds__(256) void k_sah_big_partition(const float* __restrict__ cen, int NB, const SahJob* __restrict__ qin, const int* __restrict__ n_in,
+                                                           const int* __restrict__ src, int* __restrict__ dst, int* __restrict__ order_out,
+                                                           const int* __restrict__ gcb, int* __restrict__ gsel) {
+    __shared__ int sWave[256 / 64 + 1];
+    __shared__ int sBase[3];
+    SahJob J; int j, c0, c1;
+    if (!sah_find_chunk(qin, *n_in, blockIdx.x, J, j, c0, c1)) return;
+    int* G = gsel + 8 * j;
+    const int mode = G[0], sax = G[1], sval = G[2], nl = G[3], eq_quota = G[4];
+    const int b = J.b, m = b + nl, nr = (J.e - J.b) - nl;
+    const int tid = threadIdx.x;
+    if (mode == 2) {                         // nothing moves
+        for (int k = c0 + tid; k < c1; k += 256) { const int t = src[k]; dst[k] = t; if (((k < m) ? nl : nr) <= 2) order_out[k] = t; }
+        return;
+    }
+    const float clo = ord2f(gcb[6 * j + sax]);
+    const float scale = (float)NB / (ord2f(gcb[6 * j + 3 + sax]) - clo);
+    auto classify = [&](int t, bool& is_eq) {          // plane: left or right; median: smaller / equal / larger
+        is_eq = false;
+        if (mode == 0) return max(0, min(NB - 1, (int)((cen[3 * (size_t)t + sax] - clo) * scale))) <= sval;
+        const unsigned key = (unsigned)f2ord(cen[3 * (size_t)t + sax]) ^ 0x80000000u;
+        is_eq = key == (unsigned)sval;
+        return key < (unsigned)sval;
+    };
+    // the chunk's counts: left for sure, equal to the median's key
+    int nL = 0, nE = 0;
+    for (int k = c0 + tid; k < c1; k += 256) { bool eq; const bool l = classify(src[k], eq); nL += l ? 1 : 0; nE += eq ? 1 : 0; }
+    for (int o = 32; o >= 1; o >>= 1) { nL += __shfl_xor(nL, o); nE += __shfl_xor(nE, o); }
+    if (tid == 0) { sBase[0] = 0; sBase[1] = 0; }
+    __syncthreads();
+    if ((tid & 63) == 0) { atomicAdd(&sBase[0], nL); atomicAdd(&sBase[1], nE); }
+    __syncthreads();
+    const int totL = sBase[0], totE = sBase[1];
+    __syncthreads();
+    if (tid == 0) {
+        // the equals first: how many of this chunk's go left
+        int eq_left = 0;
+        if (mode == 1 && totE > 0) { const int at = atomicAdd(&G[7], totE); eq_left = max(0, min(totE, eq_quota - at)); }
+        const int left_here = totL + eq_left, right_here = (c1 - c0) - left_here;
+        sBase[0] = atomicAdd(&G[5], left_here);
+        sBase[1] = atomicAdd(&G[6], right_here);
+        sBase[2] = eq_left;
+    }
+    __syncthreads();
+    const int baseL = sBase[0], baseR = sBase[1], eq_left = sBase[2];
+    int offL = 0, offR = 0, offE = 0;
+    for (int base = c0; base < c1; base += 256) {
+        const int k = base + tid;
+        const bool in = k < c1;
+        int t = 0;
+        bool goes_left = false, is_eq = false;
+        if (in) { t = src[k]; goes_left = classify(t, is_eq); }
+        if (mode == 1) {
+            int tE;
+            const int re = block_rank<256>(is_eq, sWave, tE);
+            if (is_eq) goes_left = (offE + re) < eq_left;
+            offE += tE;
+        }
+        int tL, tR;
+        const int rl = block_rank<256>(in && goes_left, sWave, tL);
+        const int rr = block_rank<256>(in && !goes_left, sWave, tR);
+        if (in) {
+            const int at = goes_left ? b + baseL + offL + rl : m + baseR + offR + rr;
+            dst[at] = t;
+            if ((goes_left ? nl : nr) <= 2) order_out[at] = t;
+        }
+        offL += tL; offR += tR;
+    }
+}
+
+// The next level's queues by size class: tiny nodes (3 .. tiny_max patches; one WAVE each, k_sah_level_wave), big ones (SAH_BIG and
+// more; chunk-parallel gathering passes), the rest (one 256-thread workgroup each).  tiny_max = 0: no tiny class (more than 32 bins).
+struct SahQueues { SahJob* tiny; int* n_tiny; SahJob* small; int* n_small; SahJob* big; int* n_big; int tiny_max; };
+__device__ __forceinline__ void sah_push(const SahQueues& Q, int cb, int ce, int cid) {
+    const int cn = ce - cb;
+    if (cn >= SAH_BIG) { const int at = atomicAdd(Q.n_big, 1); Q.big[at] = SahJob{ cb, ce, cid }; }
+    else if (cn > Q.tiny_max) { const int at = atomicAdd(Q.n_small, 1); Q.small[at] = SahJob{ cb, ce, cid }; }
+    else { const int at = atomicAdd(Q.n_tiny, 1); Q.tiny[at] = SahJob{ cb, ce, cid }; }
+}
+
+// TINY nodes (at most 64 patches, at most 32 bins): one wave per node, four nodes per workgroup, no workgroup barrier anywhere --
+// a lane holds one patch in registers, the centroid bounds are a butterfly over the lanes, the bins live in the wave's own piece
+// of LDS, the planes' prefix / suffix boxes are scans with lanes = bins, the partition is a ballot.  (Most nodes of a tree are
+// tiny: at 64k patches 15 of 16; one 256-thread workgroup per such node spent its time in barriers.)  Same float expressions and
+// tie rules as k_sah_level and the host builder; the median fallback ranks the centroids by counting.
+constexpr int SAH_WNB = 32;
+__global__ __launch_bounds__(256) void k_sah_level_wave(int N, const TriRec* __restrict__ tri, const float* __restrict__ cen, const double* __restrict__ diag_mean,
+                                                        float dilate, int NB, const SahJob* __restrict__ qin, const int* __restrict__ n_in, SahQueues Q,
+                                                        const int* __restrict__ src, int* __restrict__ dst, int* __restrict__ order_out,
+                                                        int* __restrict__ left, int* __restrict__ right, int* __restrict__ first, int* __restrict__ last,
+                                                        int* __restrict__ parent) {
+    __shared__ int sBins[4][3][SAH_WNB][7];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float grow = dilate * (float)diag_mean[0];
+    const int njobs = *n_in;
+    int (*B)[SAH_WNB][7] = sBins[wv];
+    for (int j = blockIdx.x * 4 + wv; j < njobs; j += gridDim.x * 4) {
+        const SahJob J = qin[j];
+        const int b = J.b, e = J.e, n = e - b;
+        const bool has = lane < n;
+        const int t = has ? src[b + lane] : 0;
+        float c[3] = { 0.0f, 0.0f, 0.0f }, blo[3] = { 0.0f, 0.0f, 0.0f }, bhi[3] = { 0.0f, 0.0f, 0.0f };
+        if (has)
+            for (int a = 0; a < 3; a++) { c[a] = cen[3 * (size_t)t + a]; blo[a] = tri[t].lo[a]; bhi[a] = tri[t].hi[a]; }
+        // ---- 1. bounds of the centroids
+        float clo[3], chi[3], scale[3];
+        bool valid[3];
+        for (int a = 0; a < 3; a++) {
+            float lo = has ? c[a] : INFINITY, hi = has ? c[a] : -INFINITY;
+            for (int o = 32; o >= 1; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+            clo[a] = lo; chi[a] = hi;
+            const float ext = hi - lo;
+            scale[a] = (float)NB / ext;
+            valid[a] = (ext > 0.0f) && isfinite(scale[a]);
+        }
+        // ---- 2. bins (this wave's own LDS; a wave's LDS operations complete in order)
+        for (int x = lane; x < 3 * NB; x += 64) {
+            int* E = B[x / NB][x % NB];
+            E[0] = 0;
+            for (int d = 0; d < 3; d++) { E[1 + d] = 0x7fffffff; E[4 + d] = (int)0x80000000; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int mybin[3] = { 0, 0, 0 };
+        if (has)
+            for (int a = 0; a < 3; a++) {
+                if (!valid[a]) continue;
+                const int q = max(0, min(NB - 1, (int)((c[a] - clo[a]) * scale[a])));
+                mybin[a] = q;
+                atomicAdd(&B[a][q][0], 1);
+                for (int d = 0; d < 3; d++) { atomicMin(&B[a][q][1 + d], f2ord(blo[d])); atomicMax(&B[a][q][4 + d], f2ord(bhi[d])); }
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- 3. the planes: lanes = bins; inclusive scans from the left and from the right
+        float best = INFINITY;
+        int best_x = 0x7fffffff, best_c = 0;
+        for (int a = 0; a < 3; a++) {
+            if (!valid[a]) continue;                    // (wave-uniform)
+            int cnt = 0;
+            float plo[3] = { INFINITY, INFINITY, INFINITY }, phi[3] = { -INFINITY, -INFINITY, -INFINITY };
+            if (lane < NB && B[a][lane][0] > 0) {
+                cnt = B[a][lane][0];
+                for (int d = 0; d < 3; d++) { plo[d] = ord2f(B[a][lane][1 + d]); phi[d] = ord2f(B[a][lane][4 + d]); }
+            }
+            int pc = cnt, sc = cnt;
+            float slo[3] = { plo[0], plo[1], plo[2] }, shi[3] = { phi[0], phi[1], phi[2] };
+            for (int o = 1; o < SAH_WNB; o <<= 1) {
+                const int upc = __shfl_up(pc, o), dsc = __shfl_down(sc, o);
+                float ulo[3], uhi[3], dlo[3], dhi[3];
+                for (int d = 0; d < 3; d++) {
+                    ulo[d] = __shfl_up(plo[d], o); uhi[d] = __shfl_up(phi[d], o);
+                    dlo[d] = __shfl_down(slo[d], o); dhi[d] = __shfl_down(shi[d], o);
+                }
+                if (lane >= o) { pc += upc; for (int d = 0; d < 3; d++) { plo[d] = fminf(plo[d], ulo[d]); phi[d] = fmaxf(phi[d], uhi[d]); } }
+                if (lane + o < SAH_WNB) { sc += dsc; for (int d = 0; d < 3; d++) { slo[d] = fminf(slo[d], dlo[d]); shi[d] = fmaxf(shi[d], dhi[d]); } }
+            }
+            // the plane between bins `lane` and `lane + 1`: left = my prefix, right = the next lane's suffix
+            const int rc = __shfl_down(sc, 1);
+            float rlo[3], rhi[3];
+            for (int d = 0; d < 3; d++) { rlo[d] = __shfl_down(slo[d], 1); rhi[d] = __shfl_down(shi[d], 1); }
+            if (lane < NB - 1 && pc > 0 && rc > 0) {
+                const float cost = sah_area(plo, phi, grow) * (float)pc + sah_area(rlo, rhi, grow) * (float)rc;
+                if (cost < best) { best = cost; best_x = a * (NB - 1) + lane; best_c = pc; }
+            }
+        }
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float c2 = __shfl_xor(best, o);
+            const int x2 = __shfl_xor(best_x, o), n2 = __shfl_xor(best_c, o);
+            if (c2 < best || (c2 == best && x2 < best_x)) { best = c2; best_x = x2; best_c = n2; }
+        }
+        // ---- the split
+        bool goes_left;
+        int nl;
+        if (best_x != 0x7fffffff) {
+            const int a = best_x / (NB - 1), q = best_x % (NB - 1);
+            goes_left = (a == 0 ? mybin[0] : (a == 1 ? mybin[1] : mybin[2])) <= q;
+            nl = best_c;
+        } else {
+            int axis = -1;
+            for (int a = 0; a < 3; a++)
+                if (chi[a] - clo[a] > 0.0f && (axis < 0 || chi[a] - clo[a] > chi[axis] - clo[axis])) axis = a;
+            nl = n / 2;
+            if (axis < 0) goes_left = lane < nl;
+            else {
+                // the exact median along `axis`: a patch's rank = how many others lie before it (ties by position)
+                const float key = axis == 0 ? c[0] : (axis == 1 ? c[1] : c[2]);
+                int rank = 0;
+                for (int m = 0; m < n; m++) {
+                    const float km = __shfl(key, m);
+                    rank += (km < key || (km == key && m < lane)) ? 1 : 0;
+                }
+                goes_left = rank < nl;
+            }
+        }
+        const int nr = n - nl, m = b + nl;
+        // ---- partition (into the other order buffer; stretches that are final also into order_out)
+        const unsigned long long ml = __ballot(has && goes_left), mr = __ballot(has && !goes_left);
+        if (has) {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const int at = goes_left ? b + __popcll(ml & below) : m + __popcll(mr & below);
+            dst[at] = t;
+            if ((goes_left ? nl : nr) <= 2) order_out[at] = t;
+        }
+        // ---- the node's record and its children
+        if (lane == 0) {
+            first[J.id] = b; last[J.id] = e - 1;
+            const int lc = nl == 1 ? N - 1 + b : J.id + 1;
+            const int rc = nr == 1 ? N - 1 + m : J.id + 1 + (nl - 1);
+            left[J.id] = lc; right[J.id] = rc; parent[lc] = J.id; parent[rc] = J.id;
+            for (int side = 0; side < 2; side++) {
+                const int cb = side ? m : b, ce = side ? e : m, cid = side ? rc : lc, cn = ce - cb;
+                if (cn == 2) {
+                    first[cid] = cb; last[cid] = cb + 1;
+                    left[cid] = N - 1 + cb; right[cid] = N - 1 + cb + 1;
+                    parent[N - 1 + cb] = cid; parent[N - 1 + cb + 1] = cid;
+                } else if (cn >= 3) sah_push(Q, cb, ce, cid);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+
+// PRE: the centroid bounds and bins of job j were formed by k_sah_big_bounds / k_sah_big_bins (gcb, gbins)
+template <int SAH_NT, bool PRE>
 __global__ __launch_bounds__(SAH_NT) void k_sah_level(int N, const TriRec* __restrict__ tri, const float* __restrict__ cen, const double* __restrict__ diag_mean,
-                                                      float dilate, int NB, const SahJob* __restrict__ qin, const int* __restrict__ n_in, SahJob* __restrict__ qout,
-                                                      int* __restrict__ n_out, const int* __restrict__ src, int* __restrict__ dst, int* __restrict__ order_out,
+                                                      float dilate, int NB, const SahJob* __restrict__ qin, const int* __restrict__ n_in, SahQueues Q,
+                                                      const int* __restrict__ src, int* __restrict__ dst, int* __restrict__ order_out,
                                                       int* __restrict__ left, int* __restrict__ right, int* __restrict__ first, int* __restrict__ last,
-                                                      int* __restrict__ parent) {
+                                                      int* __restrict__ parent, const int* __restrict__ gcb, const int* __restrict__ gbins, int* __restrict__ gsel) {
     __shared__ int sCnt[3][SAH_NBMAX];
     __shared__ int sLo[3][SAH_NBMAX][3], sHi[3][SAH_NBMAX][3];
     __shared__ int sC[6];                      // centroid bounds as ordered keys: lo[3], hi[3]
@@ -441,6 +830,7 @@ __global__ __launch_bounds__(SAH_NT) void k_sah_level(int N, const TriRec* __res
     __shared__ int sIdx[SAH_NT];
     __shared__ int sWave[SAH_NT / 64 + 1];
     __shared__ int sHist[256];
+    constexpr int U = 4;                       // patches per thread in flight in the gathering loops
     __shared__ int sSel[4];                    // split: mode (0 plane, 1 median, 2 halves as they lie), axis, bin / key, count on the left
     const int tid = threadIdx.x;
     const float grow = dilate * (float)diag_mean[0];
@@ -449,17 +839,37 @@ __global__ __launch_bounds__(SAH_NT) void k_sah_level(int N, const TriRec* __res
         const SahJob J = qin[j];
         const int b = J.b, e = J.e, n = e - b;
         // ---- 1. bounds of the centroids
-        if (tid < 6) sC[tid] = tid < 3 ? 0x7fffffff : (int)0x80000000;
-        for (int x = tid; x < 3 * SAH_NBMAX; x += SAH_NT) {
-            (&sCnt[0][0])[x] = 0;
-            for (int d = 0; d < 3; d++) { (&sLo[0][0][0])[3 * x + d] = 0x7fffffff; (&sHi[0][0][0])[3 * x + d] = (int)0x80000000; }
+        if (PRE) {
+            if (tid < 6) sC[tid] = gcb[6 * j + tid];
+            for (int x = tid; x < 3 * NB; x += SAH_NT) {
+                const int a = x / NB, q = x % NB;
+                const int* G = gbins + (size_t)j * SAH_GB + (a * SAH_NBMAX + q) * 7;
+                sCnt[a][q] = G[0];
+                for (int d = 0; d < 3; d++) { sLo[a][q][d] = G[1 + d]; sHi[a][q][d] = G[4 + d]; }
+            }
+        } else {
+            if (tid < 6) sC[tid] = tid < 3 ? 0x7fffffff : (int)0x80000000;
+            for (int x = tid; x < 3 * NB; x += SAH_NT) {
+                const int a = x / NB, q = x % NB;
+                sCnt[a][q] = 0;
+                for (int d = 0; d < 3; d++) { sLo[a][q][d] = 0x7fffffff; sHi[a][q][d] = (int)0x80000000; }
+            }
         }
         __syncthreads();
-        {
+        if (!PRE) {
             int lo3[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi3[3] = { (int)0x80000000, (int)0x80000000, (int)0x80000000 };
-            for (int k = b + tid; k < e; k += SAH_NT) {
-                const int t = src[k];
-                for (int a = 0; a < 3; a++) { const int o = f2ord(cen[3 * (size_t)t + a]); lo3[a] = min(lo3[a], o); hi3[a] = max(hi3[a], o); }
+            for (int k0 = b + tid; k0 < e; k0 += U * SAH_NT) {
+                int t[U];
+                float c[U][3];
+#pragma unroll
+                for (int u = 0; u < U; u++) { const int k = k0 + u * SAH_NT; t[u] = k < e ? src[k] : -1; }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    for (int a = 0; a < 3; a++) c[u][a] = t[u] >= 0 ? cen[3 * (size_t)t[u] + a] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (t[u] >= 0)
+                        for (int a = 0; a < 3; a++) { const int o = f2ord(c[u][a]); lo3[a] = min(lo3[a], o); hi3[a] = max(hi3[a], o); }
             }
             for (int a = 0; a < 3; a++) {
                 for (int o = 32; o >= 1; o >>= 1) { lo3[a] = min(lo3[a], __shfl_xor(lo3[a], o)); hi3[a] = max(hi3[a], __shfl_xor(hi3[a], o)); }
@@ -476,14 +886,26 @@ __global__ __launch_bounds__(SAH_NT) void k_sah_level(int N, const TriRec* __res
             valid[a] = (ext > 0.0f) && isfinite(scale[a]);
         }
         // ---- 2. bins
-        for (int k = b + tid; k < e; k += SAH_NT) {
-            const int t = src[k];
-            const TriRec T = tri[t];
-            for (int a = 0; a < 3; a++) {
-                if (!valid[a]) continue;
-                const int q = max(0, min(NB - 1, (int)((cen[3 * (size_t)t + a] - clo[a]) * scale[a])));
-                atomicAdd(&sCnt[a][q], 1);
-                for (int d = 0; d < 3; d++) { atomicMin(&sLo[a][q][d], f2ord(T.lo[d])); atomicMax(&sHi[a][q][d], f2ord(T.hi[d])); }
+        for (int k0 = b + tid; !PRE && k0 < e; k0 += U * SAH_NT) {
+            int t[U];
+            float c[U][3], blo[U][3], bhi[U][3];
+#pragma unroll
+            for (int u = 0; u < U; u++) { const int k = k0 + u * SAH_NT; t[u] = k < e ? src[k] : -1; }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                for (int a = 0; a < 3; a++) {
+                    c[u][a] = t[u] >= 0 ? cen[3 * (size_t)t[u] + a] : 0.0f;
+                    blo[u][a] = t[u] >= 0 ? tri[t[u]].lo[a] : 0.0f; bhi[u][a] = t[u] >= 0 ? tri[t[u]].hi[a] : 0.0f;
+                }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (t[u] < 0) continue;
+                for (int a = 0; a < 3; a++) {
+                    if (!valid[a]) continue;
+                    const int q = max(0, min(NB - 1, (int)((c[u][a] - clo[a]) * scale[a])));
+                    atomicAdd(&sCnt[a][q], 1);
+                    for (int d = 0; d < 3; d++) { atomicMin(&sLo[a][q][d], f2ord(blo[u][d])); atomicMax(&sHi[a][q][d], f2ord(bhi[u][d])); }
+                }
             }
         }
         __syncthreads();
@@ -539,7 +961,7 @@ __global__ __launch_bounds__(SAH_NT) void k_sah_level(int N, const TriRec* __res
                 unsigned prefix = 0u, pmask = 0u;
                 int want = n / 2;                    // rank inside the keys that match the prefix so far
                 for (int sh = 24; sh >= 0; sh -= 8) {
-                    sHist[tid] = 0;
+                    if (tid < 256) sHist[tid] = 0;
                     __syncthreads();
                     for (int k = b + tid; k < e; k += SAH_NT) {
                         const unsigned key = (unsigned)f2ord(cen[3 * (size_t)src[k] + axis]) ^ 0x80000000u;      // unsigned order
@@ -567,8 +989,13 @@ __global__ __launch_bounds__(SAH_NT) void k_sah_level(int N, const TriRec* __res
         const int m = b + nl;
         __syncthreads();
         // ---- 4. partition into the other order buffer (stretches that are final -- children of one or two patches -- also into order_out)
+        // (a big node only publishes its split: k_sah_big_partition moves its patches, one workgroup per chunk)
+        if (PRE && tid == 0) {
+            int* G = gsel + 8 * j;
+            G[0] = mode; G[1] = sax; G[2] = sval; G[3] = nl; G[4] = eq_quota; G[5] = 0; G[6] = 0; G[7] = 0;
+        }
         int offL = 0, offR = 0, offE = 0;
-        for (int base = b; base < e; base += SAH_NT) {
+        for (int base = b; !PRE && base < e; base += SAH_NT) {
             const int k = base + tid;
             const bool in = k < e;
             int t = 0;
@@ -583,13 +1010,13 @@ __global__ __launch_bounds__(SAH_NT) void k_sah_level(int N, const TriRec* __res
             }
             if (mode == 1) {
                 int totE;
-                const int re = block_rank(is_eq, sWave, totE);
+                const int re = block_rank<SAH_NT>(is_eq, sWave, totE);
                 if (is_eq) goes_left = (offE + re) < eq_quota;
                 offE += totE;
             }
             int totL, totR;
-            const int rl = block_rank(in && goes_left, sWave, totL);
-            const int rr = block_rank(in && !goes_left, sWave, totR);
+            const int rl = block_rank<SAH_NT>(in && goes_left, sWave, totL);
+            const int rr = block_rank<SAH_NT>(in && !goes_left, sWave, totR);
             if (in) {
                 const int at = goes_left ? b + offL + rl : m + offR + rr;
                 dst[at] = t;
@@ -609,67 +1036,130 @@ __global__ __launch_bounds__(SAH_NT) void k_sah_level(int N, const TriRec* __res
                     first[cid] = cb; last[cid] = cb + 1;
                     left[cid] = N - 1 + cb; right[cid] = N - 1 + cb + 1;
                     parent[N - 1 + cb] = cid; parent[N - 1 + cb + 1] = cid;
-                } else if (cn >= 3) {
-                    const int at = atomicAdd(n_out, 1);
-                    qout[at] = SahJob{ cb, ce, cid };
-                }
+                } else if (cn >= 3) sah_push(Q, cb, ce, cid);
             }
         }
         __syncthreads();
     }
 }
 
-// the queue's first job (the root, when it has three patches or more) and the trees of one and two patches
-__global__ void k_sah_seed(int N, SahJob* __restrict__ q, int* __restrict__ cnt, int* __restrict__ order_out, int* __restrict__ left, int* __restrict__ right,
-                           int* __restrict__ first, int* __restrict__ last, int* __restrict__ parent) {
+// the first job (the root, when it has three patches or more) into the queue of its size class, and the trees of one and two patches
+__global__ void k_sah_seed(int N, SahQueues Q, int* __restrict__ order_out, int* __restrict__ left, int* __restrict__ right, int* __restrict__ first,
+                           int* __restrict__ last, int* __restrict__ parent) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     parent[0] = -1;
-    cnt[0] = 0; cnt[1] = 0;
-    if (N >= 3) { q[0] = SahJob{ 0, N, 0 }; cnt[0] = 1; }
+    if (N >= 3) sah_push(Q, 0, N, 0);
     else {
         for (int k = 0; k < N; k++) order_out[k] = k;
         if (N == 2) { first[0] = 0; last[0] = 1; left[0] = 1; right[0] = 2; parent[1] = 0; parent[2] = 0; }
     }
 }
 
-// order_out, left, right, first, last, parent: the arrays k_hierarchy writes for the Morton tree (device pointers)
+// order_out, left, right, first, last, parent: the arrays k_hierarchy writes for the Morton tree (device pointers).
+// Per level two launches: the open nodes of SAH_BIG patches or more on 1024-thread workgroups (few nodes, long stretches),
+// the others on 256-thread ones; every level has its own pair of queue counters (zeroed once), so nothing is reset between
+// levels, and the host looks once per eight levels whether nodes are still open.
 static hipError_t sah_hierarchy_device(hipStream_t st, int N, const TriRec* tri, const TreeOptions& topt, int* order_out, int* left, int* right,
                                        int* first, int* last, int* parent) {
     hipError_t e = hipSuccess;
-    float* cen = nullptr; double* dmean = nullptr; int* ord = nullptr; SahJob* q = nullptr; int* cnt = nullptr;
-    const size_t qcap = (size_t)N / 3 + 2;
+    float* cen = nullptr; double* dmean = nullptr; int* ord = nullptr; SahJob* q = nullptr; int* cnt = nullptr; int* gb = nullptr;
+    char* arena = nullptr;
+    constexpr int MAXL = 1024;                                  // levels (the 1/32 rule and the median keep real trees below ~50)
+    const size_t qcap = (size_t)N / 3 + 2, qcap_big = (size_t)N / SAH_BIG + 2;
     const int NB = std::min(std::max(topt.sah_bins, 2), SAH_NBMAX);
 #define DR_TRY(x) do { e = (x); if (e != hipSuccess) goto done; } while (0)
-    DR_TRY(hipMalloc(&cen, sizeof(float) * 3 * (size_t)N));
-    DR_TRY(hipMalloc(&dmean, sizeof(double)));
-    DR_TRY(hipMalloc(&ord, sizeof(int) * 2 * (size_t)N));
-    DR_TRY(hipMalloc(&q, sizeof(SahJob) * 2 * qcap));
-    DR_TRY(hipMalloc(&cnt, sizeof(int) * 2));
-    hipLaunchKernelGGL(k_sah_prepare, dim3(1), dim3(1024), 0, st, N, tri, cen, dmean, ord);
-    DR_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_sah_seed, dim3(1), dim3(64), 0, st, N, q, cnt, order_out, left, right, first, last, parent);
-    DR_TRY(hipGetLastError());
-    if (N >= 3) {
-        const int grid = (int)std::min<size_t>(qcap, 4096);
-        for (int level = 0;; level++) {
+    {
+        size_t off = 0;
+        auto take = [&off](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+        const size_t o_cnt = take(sizeof(int) * 3 * (MAXL + 1));
+        const size_t o_cen = take(sizeof(float) * 3 * (size_t)N), o_dm = take(sizeof(double) * (1 + SAH_PREP_BLOCKS));
+        const size_t o_ord = take(sizeof(int) * 2 * (size_t)N), o_q = take(sizeof(SahJob) * (4 * qcap + 2 * qcap_big));
+        const size_t o_gb = take(sizeof(int) * qcap_big * (6 + SAH_GB + 8));
+        DR_TRY(hipMalloc(&arena, off));
+        cnt = (int*)(arena + o_cnt); cen = (float*)(arena + o_cen); dmean = (double*)(arena + o_dm); ord = (int*)(arena + o_ord);
+        q = (SahJob*)(arena + o_q); gb = (int*)(arena + o_gb);
+        DR_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * 3 * (MAXL + 1), st));
+    }
+    {
+        int* gcb = gb; int* gbins = gb + qcap_big * 6; int* gsel = gbins + qcap_big * SAH_GB;
+        // blocks of the chunk kernels: every big job has at most n / SAH_CHUNK + 1 chunks, all of them together N / SAH_CHUNK + jobs
+        const int grid_chunks = (int)((size_t)N / SAH_CHUNK + qcap_big);
+        const int grid_reset = (int)((qcap_big * SAH_GB + 255) / 256);
+        int* cnt_tiny = cnt; int* cnt_small = cnt + (MAXL + 1); int* cnt_big = cnt + 2 * (MAXL + 1);
+        SahJob* q_tiny[2] = { q, q + qcap };
+        SahJob* q_small[2] = { q + 2 * qcap, q + 3 * qcap };
+        SahJob* q_big[2] = { q + 4 * qcap, q + 4 * qcap + qcap_big };
+        const int tiny_max = NB <= SAH_WNB ? 64 : 0;
+        auto queues = [&](int buf, int level) { return SahQueues{ q_tiny[buf], cnt_tiny + level, q_small[buf], cnt_small + level, q_big[buf], cnt_big + level, tiny_max }; };
+        hipLaunchKernelGGL(k_sah_prepare, dim3(SAH_PREP_BLOCKS), dim3(256), 0, st, N, tri, cen, dmean, ord);
+        DR_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_sah_diag_mean, dim3(1), dim3(64), 0, st, N, dmean);
+        DR_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_sah_seed, dim3(1), dim3(64), 0, st, N, queues(0, 0), order_out, left, right, first, last, parent);
+        DR_TRY(hipGetLastError());
+        bool big_open = N >= SAH_BIG, small_open = true;
+        int next_look = 2;
+        while ((1ll << next_look) < N) next_look++;              // ceil(log2 N): closing nodes of two patches takes log2(N) - 1 levels at least
+        int next_look_big = 0;
+        while (((long long)SAH_BIG << next_look_big) <= N) next_look_big++;       // levels of even splits until no node has SAH_BIG patches
+        const int grid_small = (int)std::min<size_t>(qcap, 4096), grid_big = (int)std::min<size_t>(qcap_big, 256);
+        const int grid_tiny = (int)std::min<size_t>((qcap + 3) / 4, 4096);
+        for (int level = 0; N >= 3; level++) {
+            if (level >= MAXL) { e = hipErrorUnknown; goto done; }      // (cannot happen: every split leaves both sides non-empty)
             const int in = level & 1, out = in ^ 1;
-            DR_TRY(hipMemsetAsync(cnt + out, 0, sizeof(int), st));
-            hipLaunchKernelGGL(k_sah_level, dim3(grid), dim3(SAH_NT), 0, st, N, tri, cen, dmean, topt.sah_dilate, NB, q + (size_t)in * qcap, cnt + in,
-                               q + (size_t)out * qcap, cnt + out, ord + (size_t)in * N, ord + (size_t)out * N, order_out, left, right, first, last, parent);
-            DR_TRY(hipGetLastError());
-            if ((level & 7) == 7) {           // look once per eight levels whether nodes are still open
-                int open = 0;
-                DR_TRY(hipMemcpyAsync(&open, cnt + out, sizeof(int), hipMemcpyDeviceToHost, st));
+            const SahQueues Qo = queues(out, level + 1);
+            const int* src = ord + (size_t)in * N;
+            int* dst = ord + (size_t)out * N;
+            if (big_open) {
+                hipLaunchKernelGGL(k_sah_big_reset, dim3(grid_reset), dim3(256), 0, st, (int)qcap_big, gcb, gbins);
+                DR_TRY(hipGetLastError());
+                hipLaunchKernelGGL(k_sah_big_bounds, dim3(grid_chunks), dim3(256), 0, st, cen, q_big[in], cnt_big + level, src, gcb);
+                DR_TRY(hipGetLastError());
+                hipLaunchKernelGGL(k_sah_big_bins, dim3(grid_chunks), dim3(256), 0, st, tri, cen, NB, q_big[in], cnt_big + level, src, gcb, gbins);
+                DR_TRY(hipGetLastError());
+                hipLaunchKernelGGL((k_sah_level<1024, true>), dim3(grid_big), dim3(1024), 0, st, N, tri, cen, dmean, topt.sah_dilate, NB, q_big[in], cnt_big + level,
+                                   Qo, src, dst, order_out, left, right, first, last, parent, gcb, gbins, gsel);
+                DR_TRY(hipGetLastError());
+                hipLaunchKernelGGL(k_sah_big_partition, dim3(grid_chunks), dim3(256), 0, st, cen, NB, q_big[in], cnt_big + level, src, dst, order_out, gcb, gsel);
+                DR_TRY(hipGetLastError());
+            }
+            if (small_open) {
+                hipLaunchKernelGGL((k_sah_level<256, false>), dim3(grid_small), dim3(256), 0, st, N, tri, cen, dmean, topt.sah_dilate, NB, q_small[in], cnt_small + level,
+                                   Qo, src, dst, order_out, left, right, first, last, parent, nullptr, nullptr, nullptr);
+                DR_TRY(hipGetLastError());
+            }
+            if (tiny_max > 0) {
+                hipLaunchKernelGGL(k_sah_level_wave, dim3(grid_tiny), dim3(256), 0, st, N, tri, cen, dmean, topt.sah_dilate, NB, q_tiny[in], cnt_tiny + level,
+                                   Qo, src, dst, order_out, left, right, first, last, parent);
+                DR_TRY(hipGetLastError());
+            }
+            if (big_open && level == next_look_big && level != next_look) {
+                // are big nodes still open?  (each level about halves them: first asked when even splits would have ended them;
+                // their five launches per level are worth a look)
+                int open_big = 0;
+                DR_TRY(hipMemcpyAsync(&open_big, cnt_big + level + 1, sizeof(int), hipMemcpyDeviceToHost, st));
                 DR_TRY(hipStreamSynchronize(st));
-                if (open == 0) break;
-                if (level > 4096) { e = hipErrorUnknown; goto done; }     // (cannot happen: every split leaves both sides non-empty)
+                big_open = open_big != 0;
+                next_look_big += 2;
+            }
+            if (level == next_look) {         // which classes of nodes are still open?  (first when a tree over N leaves can be done)
+                next_look += 4;
+                int open[3] = { 0, 0, 0 };
+                DR_TRY(hipMemcpyAsync(&open[0], cnt_tiny + level + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+                DR_TRY(hipMemcpyAsync(&open[1], cnt_small + level + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+                DR_TRY(hipMemcpyAsync(&open[2], cnt_big + level + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+                DR_TRY(hipStreamSynchronize(st));
+                // (children are smaller than their parent: a class that is empty, with none above it open, stays empty)
+                big_open = open[2] != 0;
+                small_open = big_open || open[1] != 0;
+                if (open[0] == 0 && open[1] == 0 && open[2] == 0) break;
             }
         }
     }
     DR_TRY(hipStreamSynchronize(st));
 #undef DR_TRY
 done:
-    (void)hipFree(cen); (void)hipFree(dmean); (void)hipFree(ord); (void)hipFree(q); (void)hipFree(cnt);
+    (void)hipFree(arena);
     return e;
 }
 
@@ -811,6 +1301,18 @@ void sah_topology_from_boxes(int N, const float* boxes, SahTopology& out, const 
     out.N = N;
 }
 
+__global__ void k_sentinel(const int* __restrict__ esize, BvhNode* __restrict__ nodes, BvhNode* __restrict__ nodes_lh) {
+    if (threadIdx.x != 0) return;
+    const int n = esize[0];
+    BvhNode endn;
+    for (int a = 0; a < 3; a++) { endn.c[a] = 0.0f; endn.h[a] = INFINITY; }
+    endn.skip = (n + 1) * (int)sizeof(BvhNode);
+    endn.tri = BVH_END;
+    nodes[n] = endn;
+    for (int a = 0; a < 3; a++) { endn.c[a] = -INFINITY; endn.h[a] = INFINITY; }          // lower / upper corner form
+    nodes_lh[n] = endn;
+}
+
 hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[3], const float shi[3], float node_pad,
                       BvhNode* nodes, BvhNode* nodes_lh, TriRec* tri_sorted, int* n_nodes_out, BvhNode* path_rec, PathHdr* path_hdr,
                       const TreeOptions& topt, SahTopology* shared, BvhPair* pairs, BvhPair* pairs_lh, int* depth_out) {
@@ -818,24 +1320,40 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
     unsigned long long *keys = nullptr, *keys2 = nullptr;
     int *vals = nullptr, *vals2 = nullptr, *ibuf = nullptr;
     float* box = nullptr;
+    int* wbuf = nullptr;           // the refit's marks of written leaves (N) and their exclusive prefix sums (N + 1)
     void* tmp = nullptr;
-    size_t tmp_bytes = 0;
+    void* tmp2 = nullptr;
+    char* arena = nullptr;         // every temporary of the build in ONE allocation (an allocation costs tens of microseconds)
+    size_t tmp_bytes = 0, tmp2_bytes = 0;
     const size_t nn = 2 * (size_t)N - 1;
+    const size_t nblk = ((size_t)N + 63) / 64, nsb = (nblk + 63) / 64;      // the refit's 64-leaf blocks and blocks of 64 blocks
     float3 lo3 = make_float3(slo[0], slo[1], slo[2]);
     float3 inv3 = make_float3(shi[0] > slo[0] ? 1.0f / (shi[0] - slo[0]) : 0.0f,
                               shi[1] > slo[1] ? 1.0f / (shi[1] - slo[1]) : 0.0f,
                               shi[2] > slo[2] ? 1.0f / (shi[2] - slo[2]) : 0.0f);
 #define DR_TRY(x) do { e = (x); if (e != hipSuccess) goto done; } while (0)
-    DR_TRY(hipMalloc(&keys, sizeof(unsigned long long) * N));
-    DR_TRY(hipMalloc(&keys2, sizeof(unsigned long long) * N));
-    DR_TRY(hipMalloc(&vals, sizeof(int) * N));
-    DR_TRY(hipMalloc(&vals2, sizeof(int) * N));
-    // left,right,first,last,flags: N-1 each; parent, esize, pre: 2N-1 each; pos: N
-    DR_TRY(hipMalloc(&ibuf, sizeof(int) * (6 * (size_t)N + 4 * nn + 1)));
-    DR_TRY(hipMalloc(&box, sizeof(float) * 6 * nn));
+    {
+        // sizes of the library calls' scratch (host-only queries), then the arena's layout
+        if (!topt.sah) DR_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (unsigned int)N, 0, 64, st));
+        DR_TRY(rocprim::exclusive_scan(nullptr, tmp2_bytes, wbuf, wbuf, 0, (size_t)N + 1, rocprim::plus<int>(), st));
+        size_t off = 0;
+        auto take = [&off](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+        const size_t o_keys = take(sizeof(unsigned long long) * N), o_keys2 = take(sizeof(unsigned long long) * N);
+        const size_t o_vals = take(sizeof(int) * N), o_vals2 = take(sizeof(int) * N);
+        // left,right,first,last: N-1 each (+ one spare block of N); parent, esize, pre, items: 2N-1 each; pos: N
+        const size_t o_ibuf = take(sizeof(int) * (6 * (size_t)N + 4 * nn + 1));
+        // boxes of all nodes, then the refit's tables: pre64, suf64 (N each), blk, pre_b, suf_b (nblk each), sblk (nsb) -- 6 floats per entry
+        const size_t o_box = take(sizeof(float) * 6 * (nn + 2 * (size_t)N + 3 * nblk + nsb));
+        const size_t o_wbuf = take(sizeof(int) * (2 * (size_t)N + 2));
+        const size_t o_tmp = take(tmp_bytes ? tmp_bytes : 16), o_tmp2 = take(tmp2_bytes ? tmp2_bytes : 16);
+        DR_TRY(hipMalloc(&arena, off));
+        keys = (unsigned long long*)(arena + o_keys); keys2 = (unsigned long long*)(arena + o_keys2);
+        vals = (int*)(arena + o_vals); vals2 = (int*)(arena + o_vals2); ibuf = (int*)(arena + o_ibuf);
+        box = (float*)(arena + o_box); wbuf = (int*)(arena + o_wbuf); tmp = arena + o_tmp; tmp2 = arena + o_tmp2;
+    }
     {
         int* left = ibuf; int* right = ibuf + N; int* first = ibuf + 2 * (size_t)N;
-        int* last = ibuf + 3 * (size_t)N; int* flags = ibuf + 4 * (size_t)N; int* parent = ibuf + 5 * (size_t)N;
+        int* last = ibuf + 3 * (size_t)N; int* parent = ibuf + 5 * (size_t)N;
         int* esize = parent + nn;
         int* pre = esize + nn;
         int* pos = pre + nn;
@@ -872,18 +1390,29 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
         } else {
             hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, st, N, tri, lo3, inv3, key_mode, keys, vals);
             DR_TRY(hipGetLastError());
-            DR_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (unsigned int)N, 0, 64, st));
-            DR_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
             DR_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (unsigned int)N, 0, 64, st));
         }
-        DR_TRY(hipMemsetAsync(flags, 0, sizeof(int) * N, st));
         if (N > 1 && !sah) {
             hipLaunchKernelGGL(k_hierarchy, dim3(nb), dim3(256), 0, st, N, keys2, left, right, first, last, parent);
             DR_TRY(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_refit, dim3(nb), dim3(256), 0, st, N, tri, vals2, left, right, first, last, parent, flags,
-                           box, esize, tri_sorted, pos);
-        DR_TRY(hipGetLastError());
+        {
+            float* pre64 = box + 6 * nn; float* suf64 = pre64 + 6 * (size_t)N; float* blk = suf64 + 6 * (size_t)N;
+            float* pre_b = blk + 6 * nblk; float* suf_b = pre_b + 6 * nblk; float* sblk = suf_b + 6 * nblk;
+            int* w = wbuf; int* wsum = wbuf + N;
+            hipLaunchKernelGGL(k_refit_leaves, dim3(nb), dim3(256), 0, st, N, tri, vals2, tri_sorted, pos, box, esize, pre64, suf64, blk);
+            DR_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_refit_blocks, dim3((int)((nblk + 255) / 256)), dim3(256), 0, st, (int)nblk, blk, pre_b, suf_b, sblk);
+            DR_TRY(hipGetLastError());
+            DR_TRY(hipMemsetAsync(w, 0, sizeof(int) * (size_t)N, st));
+            hipLaunchKernelGGL(k_refit_marks, dim3((int)((nn + 255) / 256)), dim3(256), 0, st, N, first, last, parent, w);
+            DR_TRY(hipGetLastError());
+            DR_TRY(rocprim::exclusive_scan(tmp2, tmp2_bytes, w, wsum, 0, (size_t)N + 1, rocprim::plus<int>(), st));
+            if (N > 1) {
+                hipLaunchKernelGGL(k_refit_nodes, dim3(nb), dim3(256), 0, st, N, first, last, wsum, pre64, suf64, blk, pre_b, suf_b, sblk, box, esize);
+                DR_TRY(hipGetLastError());
+            }
+        }
         hipLaunchKernelGGL(k_pad_tris, dim3(1), dim3(64), 0, st, N, tri_sorted);
         DR_TRY(hipGetLastError());
         DR_TRY(hipMemsetAsync(pre, 0xff, sizeof(int) * nn, st));
@@ -896,25 +1425,17 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float slo[
             hipLaunchKernelGGL(k_paths, dim3(nb), dim3(256), 0, st, N, pos, left, right, parent, pre, items, nodes, nodes_lh, path_rec, path_hdr);
             DR_TRY(hipGetLastError());
         }
-        // nodes written = size of the root's subtree (a lone triangle is its own root leaf)
+        // nodes written = size of the root's subtree (a lone triangle is its own root leaf); behind them the sentinel the
+        // threaded walk ends on -- every skip that leaves the tree lands on it: an all-space box that every live ray hits and
+        // whose leaf code says "end" (walk_range) -- in both box forms
+        hipLaunchKernelGGL(k_sentinel, dim3(1), dim3(64), 0, st, esize, nodes, nodes_lh);
+        DR_TRY(hipGetLastError());
         DR_TRY(hipMemcpyAsync(n_nodes_out, esize, sizeof(int), hipMemcpyDeviceToHost, st));
-        DR_TRY(hipStreamSynchronize(st));
-        // the walk has no bound check: every skip that leaves the tree lands on this node, an all-space box
-        // that every live ray hits and whose leaf code says "end" (see walk_bvh)
-        BvhNode endn;
-        for (int a = 0; a < 3; a++) { endn.c[a] = 0.0f; endn.h[a] = INFINITY; }
-        endn.skip = (*n_nodes_out + 1) * (int)sizeof(BvhNode);
-        endn.tri = BVH_END;
-        DR_TRY(hipMemcpyAsync(nodes + *n_nodes_out, &endn, sizeof(BvhNode), hipMemcpyHostToDevice, st));
-        DR_TRY(hipStreamSynchronize(st));
-        for (int a = 0; a < 3; a++) { endn.c[a] = -INFINITY; endn.h[a] = INFINITY; }          // lo / hi form
-        DR_TRY(hipMemcpyAsync(nodes_lh + *n_nodes_out, &endn, sizeof(BvhNode), hipMemcpyHostToDevice, st));
         DR_TRY(hipStreamSynchronize(st));
     }
 #undef DR_TRY
 done:
-    (void)hipFree(keys); (void)hipFree(keys2); (void)hipFree(vals); (void)hipFree(vals2);
-    (void)hipFree(ibuf); (void)hipFree(box); (void)hipFree(tmp);
+    (void)hipFree(arena);
     return e;
 }
 
