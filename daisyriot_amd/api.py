@@ -37,7 +37,8 @@ EXPORTS = [
     "dr_group_assemble", "dr_group_solver_init", "dr_group_solver_step", "dr_group_solver_converge",
     "dr_group_solver_reset", "dr_group_solver_read", "dr_group_synchronize",
     "dr_comm_set_library", "dr_comm_library_info",
-    "dr_options_defaults", "dr_set_options", "dr_get_options", "dr_group_set_options",
+    "dr_options_defaults", "dr_set_options", "dr_get_options", "dr_group_set_options", "dr_debug_sah_topology_device",
+    "dr_formfactors_reserve",
 ]
 
 TREE_AUTO, TREE_LBVH, TREE_SAH = 0, 1, 2
@@ -123,6 +124,7 @@ def load_library(path=None):
     L.dr_scene_set_mesh.argtypes = [vp, vp, i, vp, i, vp, vp, i]
     L.dr_formfactors_assemble.argtypes = [vp, vp, i, C.c_float, i, i]
     L.dr_formfactors_integrand_only.argtypes = [vp]
+    L.dr_formfactors_reserve.argtypes = [vp]
     L.dr_formfactors_read_rows.argtypes = [vp, i, i, vp]
     L.dr_visibility_read_rows.argtypes = [vp, i, i, vp]
     L.dr_formfactors_load_rows.argtypes = [vp, i, i, vp]
@@ -141,6 +143,7 @@ def load_library(path=None):
     L.dr_debug_read_bvh.argtypes = [vp, vp, i]
     L.dr_debug_read_array.argtypes = [vp, i, vp, C.c_size_t]
     L.dr_debug_sah_topology.argtypes = [i, vp, vp, vp, vp, vp, vp, vp]
+    L.dr_debug_sah_topology_device.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp]
     L.dr_comm_manual.argtypes = [vp]
     L.dr_exchange_export.argtypes = [vp, vp]
     L.dr_exchange_import.argtypes = [vp, i, vp, C.c_size_t]
@@ -395,6 +398,10 @@ class Context:
     def assemble_finish(self):
         self._chk(self.L.dr_formfactors_assemble_finish(self.h), "dr_formfactors_assemble_finish")
 
+    def reserve(self):
+        """allocate this rank's shard of F now (else: on first use)"""
+        self._chk(self.L.dr_formfactors_reserve(self.h), "dr_formfactors_reserve")
+
     def integrand_only(self):
         self._chk(self.L.dr_formfactors_integrand_only(self.h), "dr_formfactors_integrand_only")
 
@@ -505,6 +512,17 @@ class Context:
         dt = np.dtype([("lo", np.float32, 3), ("hi", np.float32, 3), ("skip", np.int32), ("tri", np.int32)])
         out = np.zeros(n, dt)
         self._chk(self.L.dr_debug_read_bvh(self.h, _p(out), n), "dr_debug_read_bvh")
+        return out
+
+    def sah_topology(self, boxes):
+        """tests: the tree topology the DEVICE builder makes of N boxes [N][6] (same dict as api.sah_topology, the host's)"""
+        boxes = np.ascontiguousarray(boxes, np.float32)
+        N = boxes.shape[0]
+        out = {k: np.zeros(max(N - 1, 1), np.int32) for k in ("left", "right", "first", "last")}
+        out["order"] = np.zeros(N, np.int32)
+        out["parent"] = np.zeros(2 * N - 1, np.int32)
+        self._chk(self.L.dr_debug_sah_topology_device(self.h, N, _p(boxes), _p(out["order"]), _p(out["left"]), _p(out["right"]), _p(out["first"]),
+                                                      _p(out["last"]), _p(out["parent"])), "dr_debug_sah_topology_device")
         return out
 
     def read_array(self, which, nbytes):

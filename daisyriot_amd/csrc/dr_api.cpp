@@ -774,6 +774,12 @@ int dr_formfactors_assemble_finish(dr_context* c) {
     if (!c->split_pending) return fail(DR_ERR_STATE, "dr_formfactors_assemble_split has not been called");
     return assemble_impl(c, nullptr, c->split_K, c->split_eps, c->split_rule, 0, 1, 2);
 }
+int dr_formfactors_reserve(dr_context* c) {
+    CTX(c);
+    if (c->N <= 0) return fail(DR_ERR_STATE, "dr_scene_set_mesh has not been called");
+    return ensure_F(c);
+}
+
 int dr_formfactors_integrand_only(dr_context* c) {
     return assemble_impl(c, nullptr, 1, 0.0f, DR_RULE_INTEGRAND, 0, 0);
 }
@@ -1131,6 +1137,25 @@ int dr_debug_sah_topology(int N, const float* boxes, int32_t* order, int32_t* le
     TreeOptions topt;
     topt.sah = true; topt.sah_on_host = true; topt.sah_bins = o.sah_bins; topt.sah_dilate = o.sah_dilate; topt.sah_host_threads = o.sah_host_threads;
     sah_topology_from_boxes(N, boxes, T, topt);
+    std::memcpy(order, T.order.data(), sizeof(int) * (size_t)N);
+    if (N > 1) {
+        std::memcpy(left, T.left.data(), sizeof(int) * (size_t)(N - 1)); std::memcpy(right, T.right.data(), sizeof(int) * (size_t)(N - 1));
+        std::memcpy(first, T.first.data(), sizeof(int) * (size_t)(N - 1)); std::memcpy(last, T.last.data(), sizeof(int) * (size_t)(N - 1));
+    }
+    std::memcpy(parent, T.parent.data(), sizeof(int) * (2 * (size_t)N - 1));
+    return DR_OK;
+}
+
+int dr_debug_sah_topology_device(dr_context* c, int N, const float* boxes, int32_t* order, int32_t* left, int32_t* right, int32_t* first,
+                                 int32_t* last, int32_t* parent) {
+    CTX(c);
+    if (N < 1 || !boxes || !order || !parent || (N > 1 && (!left || !right || !first || !last)))
+        return fail(DR_ERR_INVALID, "dr_debug_sah_topology_device: N >= 1 and every array");
+    SahTopology T;
+    TreeOptions topt;
+    topt.sah = true; topt.sah_bins = c->opt.sah_bins; topt.sah_dilate = c->opt.sah_dilate;
+    hipError_t e = sah_topology_from_boxes_device(c->stream, N, boxes, T, topt);
+    if (e != hipSuccess) return fail(DR_ERR_DEVICE, "device SAH build: %s", hipGetErrorString(e));
     std::memcpy(order, T.order.data(), sizeof(int) * (size_t)N);
     if (N > 1) {
         std::memcpy(left, T.left.data(), sizeof(int) * (size_t)(N - 1)); std::memcpy(right, T.right.data(), sizeof(int) * (size_t)(N - 1));

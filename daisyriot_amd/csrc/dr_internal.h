@@ -197,6 +197,7 @@ hipError_t build_lbvh(hipStream_t st, int N, const TriRec* tri, const float scen
                       BvhPair* pairs = nullptr /* room for max(N - 1, 1): the sibling-pair form, centre / half-extent */,
                       BvhPair* pairs_lh = nullptr /* lower / upper corner */, int* depth_out = nullptr /* depth of the written tree */);
 void sah_topology_from_boxes(int N, const float* boxes /* N x {lo[3], hi[3]} */, SahTopology& out, const TreeOptions& topt);
+hipError_t sah_topology_from_boxes_device(hipStream_t st, int N, const float* boxes, SahTopology& out, const TreeOptions& topt);
 hipError_t launch_ff_tiles(hipStream_t st, const TileParams& p);
 hipError_t launch_sweep(hipStream_t st, const SweepParams& p);
 constexpr int MAX_GROUP = 16;   // devices of one in-pass-exchanging group (SweepParams::peers)

@@ -1291,6 +1291,32 @@ static void sah_hierarchy_host(int N, const TriRec* T, std::vector<int>& order, 
     parent[0] = -1;
 }
 
+// tests: the DEVICE builder on bare boxes (host arrays in and out)
+hipError_t sah_topology_from_boxes_device(hipStream_t st, int N, const float* boxes, SahTopology& out, const TreeOptions& topt) {
+    std::vector<TriRec> T((size_t)std::max(N, 0));
+    for (int i = 0; i < N; i++) {
+        std::memset(&T[i], 0, sizeof(TriRec));
+        for (int a = 0; a < 3; a++) { T[i].lo[a] = boxes[6 * (size_t)i + a]; T[i].hi[a] = boxes[6 * (size_t)i + 3 + a]; }
+    }
+    const size_t nn = 2 * (size_t)N - 1;
+    TriRec* d_tri = nullptr; int* d_i = nullptr;
+    hipError_t e = hipMalloc(&d_tri, sizeof(TriRec) * (size_t)N);
+    if (e == hipSuccess) e = hipMalloc(&d_i, sizeof(int) * (5 * (size_t)N + nn));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tri, T.data(), sizeof(TriRec) * (size_t)N, hipMemcpyHostToDevice, st);
+    int *order = d_i, *left = d_i + N, *right = d_i + 2 * (size_t)N, *first = d_i + 3 * (size_t)N, *last = d_i + 4 * (size_t)N, *parent = d_i + 5 * (size_t)N;
+    if (e == hipSuccess) e = hipMemsetAsync(d_i, 0xff, sizeof(int) * (5 * (size_t)N + nn), st);
+    if (e == hipSuccess) e = sah_hierarchy_device(st, N, d_tri, topt, order, left, right, first, last, parent);
+    out.order.assign((size_t)N, 0); out.left.assign((size_t)std::max(N - 1, 1), 0); out.right = out.left; out.first = out.left; out.last = out.left;
+    out.parent.assign(nn, -1);
+    auto get = [&](std::vector<int>& v, const int* src, size_t n) { if (e == hipSuccess && n) e = hipMemcpyAsync(v.data(), src, sizeof(int) * n, hipMemcpyDeviceToHost, st); };
+    get(out.order, order, (size_t)N); get(out.left, left, (size_t)std::max(N - 1, 0)); get(out.right, right, (size_t)std::max(N - 1, 0));
+    get(out.first, first, (size_t)std::max(N - 1, 0)); get(out.last, last, (size_t)std::max(N - 1, 0)); get(out.parent, parent, nn);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_tri); (void)hipFree(d_i);
+    out.N = N;
+    return e;
+}
+
 void sah_topology_from_boxes(int N, const float* boxes, SahTopology& out, const TreeOptions& topt) {
     std::vector<TriRec> T((size_t)std::max(N, 0));
     for (int i = 0; i < N; i++) {

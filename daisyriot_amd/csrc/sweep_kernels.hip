@@ -56,6 +56,8 @@ __device__ __forceinline__ int range_start(int y, int n, int ntiles, int taper) 
 // agent-scope release/acquire pair per block (buffer_wbl2 + buffer_inv) cost 4 % of the whole pass at 2048 blocks.
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_system(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_system(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -148,8 +150,8 @@ __device__ __forceinline__ void sweep_tail(const SweepParams& P, float* sGf, flo
             for (int s2 = 0; s2 < S; s2++) v = fmaf(Mi[s2], sGf[rl * SPAD + s2], v);
             const size_t at = (size_t)P.rank * P.cstride + (size_t)so * P.rpr + row;
             P.Rout[at] = v;
-            for (int q = 0; q < P.n_peers; q++)
-                if (P.peers[q]) P.peers[q][at] = v;              // straight into the other devices' buffers (in-pass exchange)
+            for (int q = 0; q < P.n_peers; q++)                  // straight into the other devices' buffers (in-pass exchange),
+                if (P.peers[q]) st_system(&P.peers[q][at], v);   // written through at system scope
             float* b = P.B + (size_t)so * P.rpr + row;
             *b = *b + v;
         }
@@ -157,7 +159,8 @@ __device__ __forceinline__ void sweep_tail(const SweepParams& P, float* sGf, flo
     }
     if (P.n_peers > 0 && !P.want_sums) {
         // no sums asked for, but the pass still has to say when ALL of it has landed everywhere: the same hand-off, without sums
-        __threadfence_system();
+        // (the peer stores are write-through at system scope and arrive_last waits for this wave's stores: no fence per block)
+        if (P.tune.fenced) __threadfence_system();
         if (!arrive_last(&P.tickets[0], gridDim.x, sFlag, P.tune.fenced)) return;
         publish_pass(P);
         return;
@@ -171,7 +174,7 @@ __device__ __forceinline__ void sweep_tail(const SweepParams& P, float* sGf, flo
         for (int rl = 0; rl < ROWSB; rl++) a += (double)sV[tid * ROWSB + rl];
         st_agent(&P.blk_sums[(size_t)blockIdx.x * S + tid], a);
     }
-    if (P.n_peers > 0) __threadfence_system();       // this block's stores into the peers' buffers
+    if (P.n_peers > 0 && P.tune.fenced) __threadfence_system();       // (unfenced: write-through stores + arrive_last's wait)
     if (!arrive_last(&P.tickets[0], gridDim.x, sFlag, P.tune.fenced)) return;
     if (tid < 256) {
         const int s2 = tid >> 4, j = tid & 15;
@@ -187,7 +190,7 @@ __device__ __forceinline__ void sweep_tail(const SweepParams& P, float* sGf, flo
         const size_t at = (size_t)P.rank * P.cstride + (size_t)S * P.rpr;
         reinterpret_cast<double*>(P.Rout + at)[tid] = a;
         for (int q = 0; q < P.n_peers; q++)
-            if (P.peers[q]) reinterpret_cast<double*>(P.peers[q] + at)[tid] = a;
+            if (P.peers[q]) st_system(reinterpret_cast<double*>(P.peers[q] + at) + tid, a);
     }
     if (tid == 0) P.ctl[0] = P.ctl[0] + 1;
     if (P.n_peers > 0) { __syncthreads(); publish_pass(P); }
@@ -630,7 +633,7 @@ __global__ void k_sweep_norows(SweepParams P) {
         if ((int)threadIdx.x < P.S) {
             reinterpret_cast<double*>(P.Rout + at)[threadIdx.x] = 0.0;
             for (int q = 0; q < P.n_peers; q++)
-                if (P.peers[q]) reinterpret_cast<double*>(P.peers[q] + at)[threadIdx.x] = 0.0;
+                if (P.peers[q]) st_system(reinterpret_cast<double*>(P.peers[q] + at) + threadIdx.x, 0.0);
         }
         if (threadIdx.x == 0) P.ctl[0] = P.ctl[0] + 1;
     }

@@ -149,6 +149,10 @@ int dr_scene_set_mesh(dr_context* ctx, const float* vertices, int V,
 int dr_formfactors_assemble(dr_context* ctx, const float* uv, int K,
                             float origin_eps, int rule, int keep_visibility);
 
+/* Allocates this rank's shard of F now (dr_formfactors_assemble / _load_rows do it on first use).  For hosts that want the
+ * allocation out of a timed region: a first hipMalloc of 17 GB takes 0.5 - 1 s of driver time on some machines. */
+int dr_formfactors_reserve(dr_context* ctx);
+
 /* Multi-rank assembly (no reference counterpart: the reference is single-GPU).  A pair of patches in
  * two ranks' rows is needed by both (F[i][j] and F[j][i] share the ray count); with an RCCL
  * communicator dr_formfactors_assemble traces it on one of the two ranks only and sends the
@@ -310,12 +314,15 @@ int dr_debug_read_bvh(dr_context* ctx, void* out, int max_nodes);
 /* tests: raw device arrays (0 TriRec[N] original order, 1 TriRec[N+2] Morton order,
  * 3 the uploaded (u,v) samples, 4 PatchRec[N]) */
 int dr_debug_read_array(dr_context* ctx, int which, void* out, size_t bytes);
-/* tests (host only, no device needed): the SAH tree topology dr_scene_set_mesh builds on the host from 6 144 patches up,
+/* tests (host only, no device needed): the SAH tree topology of the host's reference builder (dr_options::sah_on_host)
  * for N boxes {lo[3], hi[3]}.  order[N]: box index at each position of the leaf order; internal nodes 0 .. N-2 (0 = root)
  * with children left[i] / right[i] (>= N-1: leaf at position id - (N-1)) covering positions first[i] .. last[i];
  * parent[2N-1] (-1 for the root). */
 int dr_debug_sah_topology(int N, const float* boxes, int32_t* order, int32_t* left, int32_t* right,
                           int32_t* first, int32_t* last, int32_t* parent);
+/* tests: the same arrays from the DEVICE builder (what dr_scene_set_mesh runs), on bare boxes, with the context's options */
+int dr_debug_sah_topology_device(dr_context* ctx, int N, const float* boxes, int32_t* order, int32_t* left, int32_t* right,
+                                 int32_t* first, int32_t* last, int32_t* parent);
 
 #ifdef __cplusplus
 }

@@ -905,15 +905,20 @@ def test_alternative_walks_are_exact(mode, uv50):
             assert np.array_equal(vis, viso) and np.array_equal(_bits(F), _bits(Fo))
 
 
+@pytest.mark.parametrize("fenced", [0, 1])
 @pytest.mark.parametrize("S", [3, 9])
-def test_converge_on_a_column_split_pass(S):
+def test_converge_on_a_column_split_pass(S, fenced):
     """8192 patches on one rank: few enough row blocks that the pass cuts its columns into (tapered) ranges by itself -- the
     in-launch hand-offs (partial sums -> last range of a row block; row blocks' residual sums -> last row block) feed the
-    device-side convergence test: same pass count as the oracle, sums in the tails equal to the residual's sums"""
+    device-side convergence test: same pass count as the oracle, sums in the tails equal to the residual's sums (an
+    independent reduction: k_chunk_sums after plain passes) -- in the shipped form of the hand-offs (write-through stores +
+    ticket, a gfx950 property) and in the memory-model form (dr_options::sweep_fenced: release / acquire fences): same bits"""
     n = 8192
     sc = scenes.cornell_box(n, S=S, fluorescent=(S >= 8))
     E = sc.emission(7.0)
-    with _ctx(sc) as c:
+    with api.Context(0) as c:
+        c.set_options(sweep_fenced=fenced)
+        c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
         c.integrand_only()                                   # unoccluded F: rows sum to about 1, the materials absorb
         F = c.read_rows(0, sc.N)
         c.solver_init(E, sc.M, sc.mat_of_patch)
@@ -928,3 +933,11 @@ def test_converge_on_a_column_split_pass(S):
         c.step(2)                                            # plain passes afterwards: sums on demand
         _, R2 = c.read(B=False)
         assert np.allclose(c.residual_sums(), R2.astype(np.float64).sum(axis=0), rtol=1e-9)
+        assert c.info().sweep_ksplit > 1
+        SPLIT_KEEP[(S, fenced)] = (it, _bits(Bg).copy(), _bits(Rg).copy(), sums.copy())
+    other = SPLIT_KEEP.get((S, 1 - fenced))
+    if other is not None:
+        assert other[0] == it and np.array_equal(other[1], _bits(Bg)) and np.array_equal(other[2], _bits(Rg)) and np.array_equal(other[3], sums)
+
+
+SPLIT_KEEP = {}

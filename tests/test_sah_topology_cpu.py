@@ -1,5 +1,6 @@
-"""Host logic of the BVH build (no GPU): the SAH tree topology dr_scene_set_mesh hands to the device kernels from 6 144 patches
-up (daisyriot_amd/csrc/geom_kernels.hip: sah_hierarchy_host), through the library's host-only debug entry."""
+"""The SAH tree topology (daisyriot_amd/csrc/geom_kernels.hip): the host's reference builder (sah_hierarchy_host, no GPU needed:
+the library's host-only debug entry) and, marked gpu, the DEVICE builder dr_scene_set_mesh runs (sah_hierarchy_device) on the
+same inputs -- both must produce a full binary tree over a permutation of the boxes, logarithmic whatever the layout."""
 import time
 
 import numpy as np
@@ -92,3 +93,58 @@ def test_quad_mates_share_a_leaf_pair():
     assert len(same) > sc.N // 4
     together = sum(1 for i, j in same if abs(pos[i] - pos[j]) == 1 and t["parent"][sc.N - 1 + pos[i]] == t["parent"][sc.N - 1 + pos[j]])
     assert together == len(same)
+
+
+def test_denormal_extents_are_degenerate_axes():
+    """centroids that differ by a denormal on one axis: bins / extent overflows to inf there and (centroid - lowest) * inf would
+    be 0 * inf = NaN for the lowest centroid -- such an axis counts as having no extent (round-2 advisor finding)"""
+    n = 200
+    rs = np.random.RandomState(3)
+    c = np.zeros((n, 3), np.float32)
+    c[:, 0] = rs.random_sample(n).astype(np.float32)
+    c[1::2, 1] = np.float32(1e-40)                                        # a denormal step along y
+    c[:, 2] = (rs.randint(0, 2, n) * np.float32(1e-44)).astype(np.float32)
+    e = np.float32(0.01)
+    d = _check_tree(api.sah_topology(np.concatenate([c - e, c + e], axis=1)), n)
+    assert d <= 4 * int(np.ceil(np.log2(n)))
+    only_y = np.zeros((n, 3), np.float32)
+    only_y[1::2, 1] = np.float32(1e-40)                                   # nothing but the denormal step: the median fallback
+    d = _check_tree(api.sah_topology(np.concatenate([only_y - e, only_y + e], axis=1)), n)
+    assert d <= int(np.ceil(np.log2(n))) + 2
+
+
+def _inputs_for_the_device():
+    rs = np.random.RandomState(17)
+    out = {}
+    for n in (1, 2, 3, 7, 64, 65, 1000, 5000):
+        c = rs.random_sample((n, 3)).astype(np.float32) * 10
+        e = rs.random_sample((n, 3)).astype(np.float32) * 0.3
+        out["random-%d" % n] = np.concatenate([c - e, c + e], axis=1)
+    n = 4096
+    x = (1.01 ** np.arange(n)).astype(np.float32)
+    line = np.stack([x, np.zeros(n, np.float32), np.zeros(n, np.float32)], axis=1)
+    out["line"] = np.concatenate([line - 0.001, line + 0.001], axis=1)
+    out["pile"] = np.tile(np.array([[0, 0, 0, 1, 1, 1]], np.float32), (n, 1))
+    big_pile = np.tile(np.array([[0, 0, 0, 1, 1, 1]], np.float32), (9000, 1))           # a BIG node without a plane: median by chunks
+    big_pile[::3, 0] += 5.0
+    out["big-pile"] = big_pile
+    dn = np.zeros((300, 3), np.float32)
+    dn[1::2, 1] = np.float32(1e-40)
+    out["denormal"] = np.concatenate([dn - np.float32(0.01), dn + np.float32(0.01)], axis=1)
+    sc = scenes.cornell_box(20000, S=3)
+    out["cornell-20000"] = _boxes_of(sc)
+    return out
+
+
+@pytest.mark.gpu
+def test_device_builder_makes_valid_logarithmic_trees():
+    """the device's builder (tiny nodes: one wave each; big ones: chunk-parallel passes; the rest: a workgroup each) on random
+    boxes of every size class, on layouts that defeat binning, and on a scene: a full binary tree over a permutation, no deeper
+    than the host's reference tree plus a few levels"""
+    with api.Context(0) as c:
+        for name, boxes in _inputs_for_the_device().items():
+            n = boxes.shape[0]
+            d_dev = _check_tree(c.sah_topology(boxes), n)
+            d_host = _check_tree(api.sah_topology(boxes), n)
+            assert d_dev <= d_host + 3, (name, d_dev, d_host)
+            assert d_dev <= 6 * int(np.ceil(np.log2(max(n, 2)))), (name, d_dev)
