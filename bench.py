@@ -35,7 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_ROUNDS = ("r02", "r01")     # newest first: where committed PMC passes and the bare-read probe are looked up
+PROFILE_ROUNDS = ("r03", "r02", "r01")
 
 
 def sweep_bytes(nrows, N, S, n_mat):
@@ -125,18 +125,24 @@ def bare_read_gbs():
 
 
 def device_report(torch, index):
-    """name, size and clocks of the GPU the numbers were taken on (clocks: what rocm-smi shows right now, best effort)"""
+    """name, size and clocks of the GPU the numbers were taken on.  Clocks: the driver's sysfs tables of the card at the device's
+    PCI address (current level starred) -- read as files: no rocm-smi child process (a process that has initialised the GPU must
+    not exec, and under rocprofv3 every child has)."""
     p = torch.cuda.get_device_properties(index)
     d = {"name": p.name, "compute_units": p.multi_processor_count, "memory_GB": round(p.total_memory / 1e9, 1),
-         "max_clock_MHz": getattr(p, "clock_rate", 0) / 1e3 or None, "arch": getattr(p, "gcnArchName", None)}
+         "arch": getattr(p, "gcnArchName", None)}
     try:
-        import subprocess
-        r = subprocess.run(["rocm-smi", "-d", str(index), "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
-        j = json.loads(r.stdout)
-        card = next(iter(j.values()))
-        d["clocks_now"] = {k: v for k, v in card.items() if "clock" in k.lower() and ("sclk" in k.lower() or "mclk" in k.lower() or "fclk" in k.lower())}
-    except Exception as e:                                      # no rocm-smi / another output format: the name is what matters
-        d["clocks_now"] = "unavailable (%s)" % type(e).__name__
+        addr = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        base = os.path.join("/sys/bus/pci/devices", addr)
+        clocks = {}
+        for name in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk"):
+            levels = [l.strip() for l in open(os.path.join(base, name)).read().strip().split("\n")]
+            cur = [l for l in levels if l.endswith("*")]
+            clocks[name[7:]] = {"now": cur[0].split(":")[1].strip(" *") if cur else None, "max": levels[-1].split(":")[1].strip(" *")}
+        d["pci"] = addr
+        d["clocks"] = clocks
+    except Exception as e:                                      # no such files in this container: the name is what matters
+        d["clocks"] = "unavailable (%s)" % type(e).__name__
     return d
 
 

@@ -22,7 +22,7 @@ lines_ = [re.sub(r"//.*$", "", l).rstrip() for l in open(os.path.join(root, "dai
 sha = hashlib.sha256("\n".join(l for l in lines_ if l).encode()).hexdigest()[:16]     # code only: comments and blank lines do not count (bench.py: code_sha)
 pp = lambda k: tot[k] / pairs if k in tot else None
 wave_qc = pp("SQ_WAVE_CYCLES")
-d = {"workload": {"patches": npatch, "rays_per_pair": 50}, "kernel": "k_ff_tiles<256,false,0>", "kernel_source_sha": sha,
+d = {"workload": {"patches": npatch, "rays_per_pair": 50}, "kernel": "k_ff_tiles<256,false,3> (sibling-pair walk)", "kernel_source_sha": sha,
      "kernel_ms": sorted(ms)[len(ms) // 2], "pairs_traced": pairs,
      "per_traced_pair": {"valu_instructions": pp("SQ_INSTS_VALU"), "salu_and_branch_instructions": pp("SQ_INSTS_SALU"),
                          "scalar_loads": pp("SQ_INSTS_SMEM"), "scalar_cache_misses": pp("SQC_DCACHE_MISSES"),

@@ -42,7 +42,7 @@ res["all_kernels"] = {k: {c + "_KB_mean": sum(v) / len(v) for c, v in d.items()}
                       for k, d in vals.items()}
 json.dump(res, open(os.path.join(out, "pmc_sweep_64k.json"), "w"), indent=1)
 with open(os.path.join(out, "pmc_summary.md"), "w") as fh:
-    fh.write("# PMC passes, bench.py at N=65536 S=8 on 1 MI355X (round 2, kernel source %s)\n\n" % res["kernel_source_sha"])
+    fh.write("# PMC passes, bench.py at N=65536 S=8 on 1 MI355X (round 3, kernel source %s)\n\n" % res["kernel_source_sha"])
     fh.write("Separate `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs. Per-dispatch means in KiB as rocprofv3 reports them.\n\n")
     fh.write("| kernel | counter | dispatches | mean (KiB) |\n|---|---|---|---|\n")
     for k, d in vals.items():

@@ -1,9 +1,9 @@
 #!/bin/bash
 # HBM traffic of the pass kernel at HEAD: separate rocprofv3 --pmc passes (no tracing domains beside --kernel-trace),
 # gfx950 corrections applied by tools/pmc_sweep.py; plus the kernel-trace stats of the same command and the bare-read probe.
-# Writes gpurun_out/r02/* -- copy what should be judged into profiles/r02/.
+# Writes gpurun_out/r03/* -- copy what should be judged into profiles/r03/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/r02
+OUT=gpurun_out/r03
 rm -rf $OUT; mkdir -p $OUT
 CMD="python3 bench.py --no-cpu-baseline --no-zero-block-report --no-converge-report --steps 6 --warmup 2"
 for ctr in FETCH_SIZE WRITE_SIZE; do
