@@ -60,6 +60,9 @@ int main(int argc, char** argv) {
     opt.seed = (unsigned)reader.GetInteger("acceleration", "seed", 20191);
     opt.devices = parse_devices(devices_arg.empty() ? reader.Get("acceleration", "devices", "0") : devices_arg);
     if (opt.devices.empty()) opt.devices.push_back(0);
+    opt.exchange = reader.Get("acceleration", "exchange", "");
+    opt.tree = reader.Get("acceleration", "tree", "");
+    opt.walk = reader.Get("acceleration", "walk", "");
     const int bins = (int)reader.GetInteger("lightning", "bins", 9);
     std::string scene = reader.Get("filepaths", "scene", "UNKNOWN");
     std::string mtl_dir = reader.Get("filepaths", "mtl_dir", "testscenes/");

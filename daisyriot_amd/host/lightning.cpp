@@ -1,4 +1,6 @@
 #include "lightning.h"
+#include <initializer_list>
+#include <utility>
 
 #include <cmath>
 #include <cstdio>
@@ -135,6 +137,18 @@ public:
         // one process, all the listed GPUs: rows of F sharded over them (main.cpp:55-154 is one process too)
         chk(dr_group_create(opt.devices.data(), (int)opt.devices.size(), &grp_), "dr_group_create");
         world_ = (int)opt.devices.size();
+        if (!opt.exchange.empty() || !opt.tree.empty() || !opt.walk.empty()) {
+            dr_options o;
+            chk(dr_options_defaults(&o), "dr_options_defaults");
+            auto pick = [](const std::string& v, std::initializer_list<std::pair<const char*, int>> names, const char* key) {
+                for (const auto& n : names) if (v == n.first) return n.second;
+                throw HipError(std::string("config.ini: unknown value '") + v + "' of [acceleration] " + key);
+            };
+            if (!opt.exchange.empty()) o.group_exchange = pick(opt.exchange, { { "p2p", DR_GROUP_EXCHANGE_P2P }, { "rccl", DR_GROUP_EXCHANGE_RCCL }, { "inpass", DR_GROUP_EXCHANGE_INPASS } }, "exchange");
+            if (!opt.tree.empty()) o.tree = pick(opt.tree, { { "lbvh", DR_TREE_LBVH }, { "sah", DR_TREE_SAH } }, "tree");
+            if (!opt.walk.empty()) o.walk = pick(opt.walk, { { "threaded", DR_WALK_THREADED }, { "pairs", DR_WALK_PAIRS }, { "paths", DR_WALK_PATHS } }, "walk");
+            chk(dr_group_set_options(grp_, &o), "dr_group_set_options");
+        }
         for (int r = 0; r < world_; r++) {
             dr_context* c = nullptr;
             chk(dr_group_context(grp_, r, &c), "dr_group_context");

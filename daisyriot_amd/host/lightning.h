@@ -31,13 +31,16 @@ struct HipError : std::runtime_error { using std::runtime_error::runtime_error; 
 
 // What the reference fixes at compile time (RAYS_PER_PATCH, the srand seed, the thresholds 200 / 1e-4, one GPU), as
 // run-time options; the defaults are the reference's constants.  Filled from config.ini by daisyriot_cli:
-// [acceleration] devices, rays_per_patch, seed; [lightning] tolerance, max_passes (bins selects the wavelengths).
+// [acceleration] devices, rays_per_patch, seed, exchange, tree, walk; [lightning] tolerance, max_passes (bins selects the wavelengths).
 struct LightningOptions {
     std::vector<int> devices = { 0 };   // HIP ordinals; rows of F are sharded over them (one process, dr_group)
     int rays_per_patch = DR_RAYS_PER_PATCH;     // visual studio/Defines.h:25
     unsigned seed = 20191;                      // of the K (u,v) samples (the reference: srand(time()))
     float tolerance = -1.0f;                    // < 0: the reference's threshold of the method (200 spectral, 1e-4 RGB / BW)
     int max_passes = 100000;                    // cap of converge_lightning (the reference has none)
+    // dr_options by name ("" = the library's default): [acceleration] exchange = p2p | rccl | inpass (how a group moves the
+    // residual after a pass), tree = lbvh | sah, walk = threaded | pairs | paths -- none of them changes a result bit
+    std::string exchange, tree, walk;
 };
 
 class Lightning {

@@ -146,6 +146,13 @@ def test_cli_shards_over_several_devices_and_reads_the_extra_ini_keys(tmp_path):
     # --devices on the command line overrides the ini
     out2, d2 = _run(tmp_path, "--no-matfile", "--devices", "0,0")
     assert "sharded over 2 GPUs" in out2 and np.allclose(d1, d2, rtol=2e-6, atol=1e-9)
+    # [acceleration] exchange / tree / walk name dr_options: the residual exchanged inside the pass, the SAH tree, the threaded walk
+    (tmp_path / "config.ini").write_text(ini + "devices = 0,0,0\nexchange = inpass\ntree = sah\nwalk = threaded\n")
+    out5, d5 = _run(tmp_path, "--no-matfile")
+    assert "sharded over 3 GPUs" in out5 and p1 in out5 and np.array_equal(d3, d5)          # same bits as the peer-copy run
+    (tmp_path / "config.ini").write_text(ini + "exchange = carrier-pigeon\n")
+    r = subprocess.run([CLI, str(tmp_path / "config.ini"), "--no-matfile"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "unknown value 'carrier-pigeon'" in r.stderr
     # fewer rays, another seed: another (coarser) visibility estimate; a loose tolerance: fewer passes
     (tmp_path / "config.ini").write_text(ini + "rays_per_patch = 8\nseed = 7\n[lightning]\ntolerance = 0.05\n")
     out4, d4 = _run(tmp_path, "--no-matfile")
