@@ -2,6 +2,8 @@ import sys, os, time
 sys.path.insert(0, '.')
 import numpy as np
 from daisyriot_amd import api, scenes
+if os.environ.get("DR_LIB"):
+    api.LIB_PATH = os.environ["DR_LIB"]          # A/B of two builds of the library
 N = int(os.environ.get("NPATCH", "16384"))
 sc = scenes.cornell_box(N, S=8)
 uv = scenes.visibility_samples(50)
