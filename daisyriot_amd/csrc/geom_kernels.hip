@@ -1483,22 +1483,6 @@ __device__ __forceinline__ bool tri_hit(f3 o, f3 d, f3 a, f3 e1, f3 e2, float& t
     return (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t > 0.0f);
 }
 
-// The same test as a wave mask (each compare straight into an SGPR pair; predicates: 1 ==, 2 >, 3 >=, 4 <, 5 <=, ordered).
-// Same operations in the same order as tri_hit.
-__device__ __forceinline__ unsigned long long tri_hit_mask(f3 o, f3 d, f3 a, f3 e1, f3 e2, float& t_out) {
-    f3 p = cross3(d, e2);
-    float det = dot3(e1, p);
-    float inv = 1.0f / det;
-    f3 tv = o - a;
-    float u = dot3(tv, p) * inv;
-    f3 q = cross3(tv, e1);
-    float v = dot3(d, q) * inv;
-    float t = dot3(e2, q) * inv;
-    t_out = t;
-    return __builtin_amdgcn_fcmpf(u, 0.0f, 3) & __builtin_amdgcn_fcmpf(v, 0.0f, 3) & __builtin_amdgcn_fcmpf(u + v, 1.0f, 5) &
-           __builtin_amdgcn_fcmpf(t, 0.0f, 2);
-}
-
 // Conservative slab test of the segment [0,tmax] against a (padded) box held in SGPRs, as a wave
 // mask (v_cmp straight into an SGPR pair; predicate 5 = ordered <=).  t = (plane - org) * inv: the
 // subtraction first -- the cheaper plane*inv - org*inv (one fma per plane) cancels catastrophically for
@@ -1710,42 +1694,10 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
     return blocked_m;
 }
 
-// ---- the hand-written interior-node walk (used by walk_range and walk_pair below) ----
-#define DR_NODE_TEST(CX, CY, CZ, HX, HY, HZ)                                  \
-                "v_fma_f32 %[t0], " CX ", %[ix], %[kx]\n\t"                   \
-                "v_fma_f32 %[t1], " CY ", %[iy], %[ky]\n\t"                   \
-                "v_fma_f32 %[t2], " CZ ", %[iz], %[kz]\n\t"                   \
-                "v_fma_f32 %[t3], " HX ", -|%[ix]|, %[t0]\n\t"                \
-                "v_fma_f32 %[t0], " HX ", |%[ix]|, %[t0]\n\t"                 \
-                "v_fma_f32 %[t4], " HY ", -|%[iy]|, %[t1]\n\t"                \
-                "v_fma_f32 %[t1], " HY ", |%[iy]|, %[t1]\n\t"                 \
-                "v_fma_f32 %[t5], " HZ ", -|%[iz]|, %[t2]\n\t"                \
-                "v_fma_f32 %[t2], " HZ ", |%[iz]|, %[t2]\n\t"                 \
-                "v_max3_f32 %[t3], %[t3], %[t4], %[t5]\n\t"                   \
-                "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t"                   \
-                "v_max_f32_e32 %[t3], 0, %[t3]\n\t"                           \
-                "v_min_f32_e32 %[t0], %[t0], %[tmax]\n\t"                     \
-                "v_cmp_le_f32_e32 vcc, %[t3], %[t0]\n\t"                      \
-                "s_and_b64 vcc, vcc, %[alive]\n\t"
-// The same test when all live rays of the wave point into one octant (a pair's 50 rays nearly always do): with the node
-// as lower / upper corner (bvh_lh) the near and far plane of every axis are known by name, 6 fused multiply-adds
-// instead of 9: tn = fma(near, iv, k), tf = fma(far, iv, k) per axis, accept iff max(tn, 0) <= min(tf, tmax).  Same
-// rounding budget as above (two roundings of (|plane| + |org|)|iv| each), same grown boxes: conservative.
-// N?/F? = the registers that hold the near / far corner's coordinates for the wave's sign pattern.
-#define DR_NODE_TEST_S(NX, NY, NZ, FX, FY, FZ)                                \
-                "v_fma_f32 %[t3], " NX ", %[ix], %[kx]\n\t"                   \
-                "v_fma_f32 %[t4], " NY ", %[iy], %[ky]\n\t"                   \
-                "v_fma_f32 %[t5], " NZ ", %[iz], %[kz]\n\t"                   \
-                "v_fma_f32 %[t0], " FX ", %[ix], %[kx]\n\t"                   \
-                "v_fma_f32 %[t1], " FY ", %[iy], %[ky]\n\t"                   \
-                "v_fma_f32 %[t2], " FZ ", %[iz], %[kz]\n\t"                   \
-                "v_max3_f32 %[t3], %[t3], %[t4], %[t5]\n\t"                   \
-                "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t"                   \
-                "v_max_f32_e32 %[t3], 0, %[t3]\n\t"                           \
-                "v_min_f32_e32 %[t0], %[t0], %[tmax]\n\t"                     \
-                "v_cmp_le_f32_e32 vcc, %[t3], %[t0]\n\t"                      \
-                "s_and_b64 vcc, vcc, %[alive]\n\t"
-// The two tests as the walk from the root uses them (suffix X): EXEC holds the live rays while the walk runs, so the compare's
+// ---- the node tests of the hand-written walks (walk_range, walk_pairs, stream_path_records below) ----
+// The node test in its two forms -- general (X: centre / half-extent) and sign-specialised (SX: lower / upper corner, when all live
+// rays of the wave point into one octant: near and far plane of every axis known by name, 6 fused multiply-adds instead of 9).
+// EXEC holds the live rays while a walk runs, so the compare's
 // VCC needs no s_and with the liveness mask and the branch reads VCCZ; and the ray parameter is in units of the ray's own
 // length (iv, k scaled per ray by s <= 1/tmax, see k_ff_tiles), so that the VOP3 `clamp` bit does the two end clamps for free:
 //     N = max3(clamp(tn_x), tn_y, tn_z)   = max(tn_x, tn_y, tn_z, 0) unless tn_x > 1, where F <= 1 < ... rejects either way
@@ -2194,7 +2146,6 @@ __device__ __forceinline__ void lane_push(int& stk, unsigned& sp, int item) {
                  : [stk] "+v"(stk), [sp] "+s"(sp) : [it] "s"(item) : "m0", "scc");
 }
 
-#undef DR_NODE_TEST
 
 // STATS builds count BVH visits with global atomics inside the pair loop; that store makes
 // the compiler give up scalar (SMEM) loads for nodes and triangles, so it is a separate,
