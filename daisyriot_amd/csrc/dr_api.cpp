@@ -607,13 +607,14 @@ static int assemble_launch(dr_context* c, int K, float eps, int rule, int trace,
         p.uv = c->d_uv; p.pairs_traced = c->d_counter;
         // dr_options::octant_test = 0: the general node test for every pair (A/B runs)
         p.bvh_lh = c->opt.octant_test ? c->d_bvh_lh : nullptr;
-        // the walk: over the sibling-pair records unless the tree is deeper than its stack (one item per level; with path
-        // records up to one per level of each of the two paths) or the options say threaded
-        const bool deep = 2 * c->tree_depth > PAIR_STACK - 2;
-        const bool pw = c->opt.walk != DR_WALK_THREADED && !deep;
+        // the walk: over the sibling-pair records unless the tree is deeper than the walk's stack of PAIR_STACK items (or the
+        // options say threaded).  From the root the stack holds at most one item per level; with path records at most
+        // (levels of lo's path) + (levels the walk adds below a popped sibling of hi's path, or hi's own levels) + the two leaves
+        // <= 2 * depth + 2 -- deeper trees fall back from path records to the walk from the root, and from that to the threaded tree
+        const bool pw = c->opt.walk != DR_WALK_THREADED && c->tree_depth <= PAIR_STACK - 2;
         p.pairs = pw ? c->d_pairs : nullptr; p.pairs_lh = (pw && p.bvh_lh) ? c->d_pairs_lh : nullptr;
         // ... its stack filled from the two patches' path records when those were built (dr_options::walk = PATHS at set_mesh)
-        { const bool on = pw && c->opt.walk == DR_WALK_PATHS && c->d_path_rec && c->d_path_hdr;
+        { const bool on = pw && c->opt.walk == DR_WALK_PATHS && c->d_path_rec && c->d_path_hdr && 2 * c->tree_depth + 2 <= PAIR_STACK;
           p.path_rec = on ? c->d_path_rec : nullptr; p.path_hdr = on ? c->d_path_hdr : nullptr; }
         c->walk_used = !pw ? DR_WALK_THREADED : (p.path_hdr ? DR_WALK_PATHS : DR_WALK_PAIRS);
         p.vx_mode = vx_mode; p.vx_rank = c->rank; p.vx_tiles_per_rank = c->rpr / TILE; p.vsend = c->d_vsend; p.vrecv = c->d_vrecv;

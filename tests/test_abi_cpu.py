@@ -158,3 +158,34 @@ def test_tile_kernel_walk_has_no_spill_reloads_around_it():
     assert rep["pairs_kernel_found"] == "1" and rep["pairs_walk_blocks"] == "1"
     assert rep["pairs_walk_entry_spill_ops"] == "0" and rep["pairs_walk_exit_spill_ops"] == "0"
     assert rep["pairs_node_test_valu"] == "9"
+
+
+def test_options_defaults_come_from_the_environment_and_nowhere_else(monkeypatch):
+    """dr_options_defaults (pure host code): the built-in defaults, overridden by the DR_* variables -- the one place the
+    library reads them; and the product sources hold no other getenv (DR_RCCL_LIB apart: the RCCL binding is per process)"""
+    for k in [k for k in os.environ if k.startswith("DR_")]:
+        monkeypatch.delenv(k)
+    d = api.options_defaults().as_dict()
+    assert (d["tree"], d["walk"], d["octant_test"], d["sah_bins"], d["sweep_mfma"], d["group_exchange"]) == (0, 0, 1, 32, 1, 0)
+    assert d["sweep_ksplit"] == 0 and d["sweep_taper"] == -1 and d["debug_pair_lo"] == -1 and d["fault_assemble_rank"] == -1
+    monkeypatch.setenv("DR_BVH", "lbvh"); monkeypatch.setenv("DR_WALK", "paths"); monkeypatch.setenv("DR_SAH_BINS", "64")
+    monkeypatch.setenv("DR_SWEEP_KSPLIT", "3"); monkeypatch.setenv("DR_GROUP_EXCHANGE", "inpass"); monkeypatch.setenv("DR_OCTANT", "0")
+    monkeypatch.setenv("DR_DEBUG_PAIR", "5,9,2"); monkeypatch.setenv("DR_SAH_DILATE", "0.25")
+    e = api.options_defaults().as_dict()
+    assert (e["tree"], e["walk"], e["sah_bins"], e["sweep_ksplit"], e["group_exchange"], e["octant_test"]) == \
+           (api.TREE_LBVH, api.WALK_PATHS, 64, 3, api.GROUP_EXCHANGE_INPASS, 0)
+    assert (e["debug_pair_lo"], e["debug_pair_hi"], e["debug_ray"]) == (5, 9, 2) and abs(e["sah_dilate"] - 0.25) < 1e-7
+    csrc = os.path.join(ROOT, "daisyriot_amd", "csrc")
+    for name in os.listdir(csrc):
+        if not name.endswith((".cpp", ".hip", ".h")):
+            continue
+        text = open(os.path.join(csrc, name), encoding="utf-8", errors="replace").read()
+        n = text.count("getenv(")
+        if name == "dr_api.cpp":
+            a = text.index("void options_from_env(dr_options* o) {")
+            b = text.index("int check_options(const dr_options* o)")
+            assert text[:a].count("getenv(") == 0 and text[b:].count("getenv(") == 0, "getenv outside options_from_env"
+        elif name == "dr_comm.cpp":
+            assert n == 1 and 'getenv("DR_RCCL_LIB")' in text
+        else:
+            assert n == 0, name

@@ -941,3 +941,58 @@ def test_converge_on_a_column_split_pass(S, fenced):
 
 
 SPLIT_KEEP = {}
+
+
+@pytest.mark.parametrize("n", [4095, 4097, 6144, 8191])
+def test_sah_builder_size_classes_give_exact_rows(n, uv50):
+    """the device's SAH builder around its size thresholds (a root that is just / just not a BIG node, the default's switch-over
+    at 6 144 patches, a ragged last tile) and the pair walk on its trees: sampled rows of the ray counts and of F equal the
+    oracle's (its own BVH), bit for bit"""
+    sc = scenes.cornell_box(n, S=3)
+    m = _mesh(sc)
+    with api.Context(0) as c:
+        c.set_options(tree=api.TREE_SAH)
+        c.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+        i = c.info()
+        assert i.tree_used == api.TREE_SAH and i.tree_on_host == 0
+        c.assemble(uv50, keep_visibility=True)
+        assert c.info().walk_used == api.WALK_PAIRS
+        for r in np.linspace(0, n - 2, 5).astype(int):
+            Fo, viso, _ = ob.assemble_rows(m, uv50, row0=int(r), nrows=2, bvh=True)
+            assert np.array_equal(c.read_visibility(int(r), 2), viso), (n, r)
+            assert np.array_equal(_bits(c.read_rows(int(r), 2)), _bits(Fo)), (n, r)
+
+
+def test_group_in_pass_exchange_through_resets_and_mixed_calls(uv50):
+    """the in-pass exchange keeps its pass numbers straight through every call order a viewer produces: steps, a reset, a converge
+    that stops early (passes queued behind the converged one do nothing but still publish), more steps, a second converge --
+    the same bits as one context doing the same calls"""
+    sc = scenes.cornell_box(1300, S=8, fluorescent=True)
+    E = sc.emission(7.0)
+
+    def script(x):
+        out = []
+        x.step(3); out.append(x.read())
+        x.reset()
+        out.append(x.converge(5.0, per_bin=False, max_iters=40)); out.append(x.read())
+        x.step(2); out.append(x.read())
+        out.append(x.converge(0.5, per_bin=False, max_iters=300)); out.append(x.read())
+        x.reset(); x.step(1); out.append(x.read())
+        return out
+
+    with _ctx(sc) as c:
+        c.assemble(uv50)
+        c.solver_init(E, sc.M, sc.mat_of_patch)
+        want = script(c)
+    with api.Group([0, 0, 0]) as g:
+        g.set_options(group_exchange=api.GROUP_EXCHANGE_INPASS)
+        g.set_mesh(sc.vertices, sc.normals, sc.tri_v, sc.tri_n)
+        g.assemble(uv50)
+        g.solver_init(E, sc.M, sc.mat_of_patch)
+        got = script(g)
+    assert 3 < want[1] < 40 and 0 < want[4] < 300
+    for a, b in zip(want, got):
+        if isinstance(a, tuple):
+            assert np.allclose(a[0], b[0], rtol=2e-6, atol=1e-12) and np.allclose(a[1], b[1], rtol=2e-6, atol=1e-12)
+        else:
+            assert a == b
