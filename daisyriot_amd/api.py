@@ -108,7 +108,10 @@ def load_library(path=None):
                              "(make -C daisyriot_amd/csrc). There is no CPU fallback." % path)
     tdir = _torch_rocm_dir()
     if tdir and "torch" not in sys.modules:
-        C.CDLL(os.path.join(tdir, "libamdhip64.so"), mode=C.RTLD_GLOBAL)     # SONAME libamdhip64.so.7: what our NEEDED entry asks for
+        try:
+            C.CDLL(os.path.join(tdir, "libamdhip64.so"), mode=C.RTLD_GLOBAL)     # SONAME libamdhip64.so.7: what our NEEDED entry asks for
+        except OSError:
+            tdir = None          # a wheel whose runtime does not load on its own: the system's ROCm, as a C++ host would use
     L = C.CDLL(path, mode=C.RTLD_GLOBAL)
     L.dr_comm_set_library.argtypes = [C.c_char_p]
     L.dr_comm_library_info.argtypes = [C.c_char_p, C.c_size_t]
