@@ -3,10 +3,17 @@ the vector pipe's cycles its instructions fill.  usage: pmc_asm.py <dir with run
 import csv, glob, collections, hashlib, json, os, re, sys
 out = sys.argv[1]
 tot = collections.defaultdict(float)
+rows_k = collections.defaultdict(float)          # k_row_lists (walk = lists), same counters
 for f in glob.glob(os.path.join(out, "run*", "**", "*counter_collection.csv"), recursive=True):
+    per_run = collections.defaultdict(float)     # summed over the run's dispatches (walk = lists launches the rows in batches)
+    per_run_k = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
         if "k_ff_tiles" in r["Kernel_Name"]:
-            tot[r["Counter_Name"]] = max(tot[r["Counter_Name"]], float(r["Counter_Value"]))
+            per_run[r["Counter_Name"]] += float(r["Counter_Value"])
+        elif "k_row_lists" in r["Kernel_Name"]:
+            per_run_k[r["Counter_Name"]] += float(r["Counter_Value"])
+    for k, v in per_run.items(): tot[k] = max(tot[k], v)
+    for k, v in per_run_k.items(): rows_k[k] = max(rows_k[k], v)
 ms, pairs, npatch = [], None, None
 for f in glob.glob(os.path.join(out, "run*.log")):
     m = re.search(r"RES (\d+) ms ([0-9.]+) traced (\d+)", open(f).read())
@@ -15,6 +22,8 @@ for f in glob.glob(os.path.join(out, "run*.log")):
 if not pairs or not tot:
     sys.exit("no counters / no RES line under " + out)
 lines = ["%-24s %16.0f  per pair %10.1f" % (k, tot[k], tot[k] / pairs) for k in sorted(tot)]
+if rows_k:
+    lines += ["k_row_lists:"] + ["%-24s %16.0f  per pair %10.1f" % (k, rows_k[k], rows_k[k] / pairs) for k in sorted(rows_k)]
 open(os.path.join(out, "summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
