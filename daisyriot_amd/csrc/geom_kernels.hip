@@ -1653,8 +1653,8 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
         // tri_hit (same operations, same order, same values) with the division moved behind two exact exclusion tests on the
         // NUMERATORS: u = au * fl(1/det) lies outside [0, 1] for sure when |au| > |det| (1 + 2^-21) (then |u| > 1 after both
         // roundings, or is infinite) or when au and det differ in sign and |au| > 2^-100 |det| (then u < 0 strictly: the product
-        // cannot underflow to -0, and au = 0 -- whose u = -0 passes u >= 0 -- is never excluded); the same for v, which a hit also needs in [0, 1] (v >= 0, and u + v <= 1 with u >= 0).  Only when
-        // some live lane survives both is the gate formed, and only when some lane passes that too 1/det (11 instructions) and
+        // cannot underflow to -0, and au = 0 -- whose u = -0 passes u >= 0 -- is never excluded); the same for v, which a hit also needs in [0, 1] (v >= 0, and u + v <= 1 with u >= 0); then the sign of t (below).  Only when
+        // some live lane survives all three is the gate formed, and only when some lane passes that too 1/det (11 instructions) and
         // u, v, u + v, t tested as the definition says.
         const f3 pv = cross3(dn, te2);
         const float det = dot3(te1, pv);
@@ -1671,6 +1671,14 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
                                          (__builtin_amdgcn_ballot_w64((__float_as_int(av) ^ __float_as_int(det)) < 0) & __builtin_amdgcn_fcmpf(fabsf(av), m_lo, 2));
         cm &= ~out_v;
         if (cm == 0ull) continue;
+        // t = tn * fl(1/det) > 0 needs tn and det of one sign and tn != 0 (fl(1/det) has det's sign whatever its rounding, a
+        // product of opposite signs is negative or -0, and 0 * anything is 0 or NaN): the third exclusion test, on the numerator
+        // the definition forms anyway.  It ends nearly every test that comes this far -- most of those are of the ray's own source
+        // patch, whose plane the ray leaves at t = -eps
+        const float tn = dot3(te2, qv);
+        const unsigned long long out_t = __builtin_amdgcn_ballot_w64((__float_as_int(tn) ^ __float_as_int(det)) < 0) | __builtin_amdgcn_fcmpf(tn, 0.0f, 1);
+        cm &= ~out_t;
+        if (cm == 0ull) continue;
         // the gate (the second triangle of a quad has the first one's box bit for bit: the same mask)
         unsigned long long gm;
         if (c == 1 && same_gate && have_first) gm = gm_first;
@@ -1685,7 +1693,7 @@ __device__ __forceinline__ unsigned long long leaf_blocked_mask(const TriRec* __
         const float u = au * idet, v = av * idet;
         const unsigned long long vm = cm & __builtin_amdgcn_fcmpf(u, 0.0f, 3) & __builtin_amdgcn_fcmpf(v, 0.0f, 3) & __builtin_amdgcn_fcmpf(u + v, 1.0f, 5);
         if (vm == 0ull) continue;
-        const float tt = dot3(te2, qv) * idet;
+        const float tt = tn * idet;
         const unsigned long long hm = vm & __builtin_amdgcn_fcmpf(tt, 0.0f, 2);
         // closest hit is not `hi`: something nearer, or an equal-t hit of lower id
         const unsigned long long bm = hm & (__builtin_amdgcn_fcmpf(tt, tmax, 4) | (tk < hi ? __builtin_amdgcn_fcmpf(tt, tmax, 1) : 0ull));

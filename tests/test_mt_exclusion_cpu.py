@@ -83,3 +83,40 @@ def test_special_values():
     zero = a.ravel() == 0
     u = u_of(a.ravel(), d.ravel())
     assert not (ex & zero & in_unit(u)).any()
+
+
+# ---- the third exclusion test: the sign of t's numerator ----------------------------------------
+def t_excluded(a, d):
+    """leaf_blocked_mask's rule for t = fl(a * fl(1/d)): numerator and determinant of opposite sign, or a zero numerator"""
+    a, d = a.astype(np.float32), d.astype(np.float32)
+    return ((a.view(np.int32) ^ d.view(np.int32)) < 0) | (a == np.float32(0.0))
+
+
+def _check_t(a, d):
+    ex = t_excluded(a, d)
+    t = u_of(a, d)                       # the same two operations: fl(a * fl(1/d))
+    with np.errstate(all="ignore"):
+        bad = ex & (t > np.float32(0.0))
+    assert not bad.any(), (a[bad][:5], d[bad][:5], t[bad][:5])
+    return ex
+
+
+def test_sign_rule_for_t_never_excludes_a_positive_t():
+    """A hit needs t > 0 strictly.  With r = fl(1/d) of d's sign (also when it overflows, or d is a denormal or zero), a product
+    of opposite signs is negative or -0 and a zero numerator gives 0 or NaN: never > 0.  Random values of every magnitude,
+    the neighbourhood of zero, and the special values."""
+    rs = np.random.RandomState(3)
+    n = 4_000_000
+    for spread in (3, 60, 149):
+        ea, ed = rs.uniform(-spread, min(spread, 127), n), rs.uniform(-spread, min(spread, 127), n)
+        a = (rs.choice([-1.0, 1.0], n) * rs.uniform(1, 2, n) * 2.0 ** ea).astype(np.float32)
+        d = (rs.choice([-1.0, 1.0], n) * rs.uniform(1, 2, n) * 2.0 ** ed).astype(np.float32)
+        ex = _check_t(a, d)
+        assert 0.4 < ex.mean() < 0.6
+    vals = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-40, -1e-40, 1.1754944e-38, -1.1754944e-38, 1e-20, -1e-20, 1.0, -1.0, 3.0, -3.0,
+                     1e20, -1e20, 3.4028235e38, -3.4028235e38, np.inf, -np.inf, np.nan], np.float32)
+    a, d = np.meshgrid(vals, vals)
+    ex = _check_t(a.ravel(), d.ravel())
+    # and it is not vacuous where it matters: same sign, both finite and not tiny -> kept
+    keep = ~t_excluded(np.array([1e-3, -2.0], np.float32), np.array([5.0, -1e-6], np.float32))
+    assert keep.all()
