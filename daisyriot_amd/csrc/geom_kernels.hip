@@ -1902,6 +1902,10 @@ __device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restri
 // (leaf_blocked_mask runs as compiled code), the walk resumes by popping.  Same node tests as the threaded walk (DR_NODE_TEST_SX
 // per octant, DR_NODE_TEST_X for mixed signs), same grown boxes: equally conservative; what is hit is decided per triangle.
 // Stack depth: at most one pending item per level of the tree; the host only selects this walk for trees of depth <= PAIR_STACK - 2.
+// The item to do next never leaves the record's registers: the loop has two entries, one for an item in the right child's item
+// register (A6: also where a pop lands) and one for the left child's (B6), each loading the next record over the very registers
+// that held its offset -- no copy into an offset register and no jump back to a common head (the kernel is bound by the
+// instructions it issues, scalar ones included: profiles/r03/assembly_notes.md section 8).
 // ---------------------------------------------------------------------------------------
 #define DR_PWALK_VARIANT(V, BVH, TESTL, TESTR)                                                                          \
                 V "0:\n\t"                                                                                              \
@@ -1909,26 +1913,40 @@ __device__ __forceinline__ unsigned long long walk_range(const BvhNode* __restri
                 "s_cbranch_scc1 98f\n\t"                                                                                \
                 "s_add_u32 m0, m0, -1\n\t"                                                                              \
                 "s_nop 0\n\t"                                                                                           \
-                "v_readlane_b32 %[off], %[stk], m0\n"                                                                   \
-                V "1:\n\t"                                                                                              \
-                "s_cmp_lt_i32 %[off], 0\n\t"                                                                            \
-                "s_cbranch_scc1 99f\n\t"                                                                                \
-                "s_load_dwordx16 " DR_AB_ALL ", " BVH ", %[off] offset:0x0\n\t"                                         \
+                "v_readlane_b32 " DR_A6 ", %[stk], m0\n"                                                                \
+                V "1:\n\t"                           /* the item to do is in A6 (popped, or the right child's) */        \
+                "s_cmp_lt_i32 " DR_A6 ", 0\n\t"                                                                         \
+                "s_cbranch_scc1 " V "5f\n\t"                                                                            \
+                "s_load_dwordx16 " DR_AB_ALL ", " BVH ", " DR_A6 " offset:0x0\n\t"                                      \
                 "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
                 TESTL                                                                                                   \
-                "s_cbranch_vccz " V "4f\n\t"                                                                            \
+                "s_cbranch_vccz " V "7f\n\t"                                                                            \
                 TESTR                                                                                                   \
-                "s_cbranch_vccz " V "3f\n\t"                                                                            \
+                "s_cbranch_vccz " V "2f\n\t"                                                                            \
                 "v_writelane_b32 %[stk], " DR_A6 ", m0\n\t"                                                             \
                 "s_add_u32 m0, m0, 1\n"                                                                                 \
-                V "3:\n\t"                                                                                              \
-                "s_mov_b32 %[off], " DR_B6 "\n\t"                                                                       \
-                "s_branch " V "1b\n"                                                                                    \
-                V "4:\n\t"                                                                                              \
+                V "2:\n\t"                           /* the item to do is in B6 (the left child's) */                    \
+                "s_cmp_lt_i32 " DR_B6 ", 0\n\t"                                                                         \
+                "s_cbranch_scc1 " V "6f\n\t"                                                                            \
+                "s_load_dwordx16 " DR_AB_ALL ", " BVH ", " DR_B6 " offset:0x0\n\t"                                      \
+                "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+                TESTL                                                                                                   \
+                "s_cbranch_vccz " V "7f\n\t"                                                                            \
+                TESTR                                                                                                   \
+                "s_cbranch_vccz " V "2b\n\t"                                                                            \
+                "v_writelane_b32 %[stk], " DR_A6 ", m0\n\t"                                                             \
+                "s_add_u32 m0, m0, 1\n\t"                                                                               \
+                "s_branch " V "2b\n"                                                                                    \
+                V "7:\n\t"                           /* the left child is missed */                                     \
                 TESTR                                                                                                   \
                 "s_cbranch_vccz " V "0b\n\t"                                                                            \
+                "s_branch " V "1b\n"                                                                                    \
+                V "5:\n\t"                                                                                              \
                 "s_mov_b32 %[off], " DR_A6 "\n\t"                                                                       \
-                "s_branch " V "1b\n"
+                "s_branch 99f\n"                                                                                        \
+                V "6:\n\t"                                                                                              \
+                "s_mov_b32 %[off], " DR_B6 "\n\t"                                                                       \
+                "s_branch 99f\n"
 // the left child is the record's first half = register set B, the right child set A
 #define DR_PWALK_OCTANT(V, SX, SY, SZ)                                                                                  \
         DR_PWALK_VARIANT(V, "%[bvhlh]",                                                                                 \
