@@ -550,6 +550,36 @@ def test_bench_size_64k_properties(uv50):
         assert (np.abs(R1[50000:50064] - Ro) / (np.abs(Ro).max(axis=0) + 1e-30)).max() < 2e-5
 
 
+def test_one_card_holds_196k_patches(uv50):
+    """A scene three times the bench's on ONE card: 196 608 patches, dense F = 154.6 GB of the 288 (+ 38.7 GB of ray counts kept for
+    the test).  Spot rows against the oracle (exact), transpose symmetry of the ray counts far from the diagonal, closed-room row
+    sums, and one light pass of sampled rows against the oracle."""
+    sc = scenes.cornell_box(196608, S=8)
+    N = sc.N
+    assert N == 196608
+    E = sc.emission(7.0)
+    m = _mesh(sc)
+    with _ctx(sc) as c:
+        c.assemble(uv50, keep_visibility=True)
+        info = c.info()
+        assert info.bytes_F == 4 * N * N
+        for r in (1, 98765, N - 2):
+            Fo, viso, _ = ob.assemble_rows(m, uv50, row0=r, nrows=2, bvh=True)
+            assert np.array_equal(c.read_visibility(r, 2), viso), r
+            assert np.array_equal(_bits(c.read_rows(r, 2)), _bits(Fo)), r
+        va, vb = c.read_visibility(3000, 64)[:, 150016:150080], c.read_visibility(150016, 64)[:, 3000:3064]
+        assert np.array_equal(va, vb.T)
+        rows = c.read_rows(60000, 128)
+        assert np.isfinite(rows).all() and (rows >= 0).all() and 0.9 < rows.sum(axis=1).mean() < 1.1
+        c.solver_init(E, sc.M, sc.mat_of_patch)
+        c.step(1)
+        _, R1 = c.read()
+        Fs = c.read_rows(170000, 64)
+        Bo = E[170000:170064].copy()
+        Ro = ob.sweep_rows(Fs, sc.M, sc.mat_of_patch, E, Bo, row0=170000)
+        assert (np.abs(R1[170000:170064] - Ro) / (np.abs(Ro).max(axis=0) + 1e-30)).max() < 2e-5
+
+
 def test_c5_shard_256k_fluorescent(uv50):
     """BASELINE.json's largest configuration on one card: 262 144 patches, 8 bins with fluorescent cross-bin
     transfer, rank 5 of an 8-way row shard (32 768 x 262 144 floats = 34.4 GB of F).  Spot rows against the
